@@ -1,0 +1,719 @@
+// gprc_api.hip -- the C ABI declared in include/gprc_native.h, composed from the gfx950 launchers.
+//
+// Host side of the hot path (reference R/GPRclass.R:127-170, R/GPCclass.R:66-115): owns device
+// memory through opaque handles, stages host arrays when the caller hands over host pointers (the
+// `.Call` case) and uses device pointers in place (the resident-data case).  No CPU arithmetic on
+// matrices happens here: without a gfx950 device every entry point fails with GPRC_ERR_NO_DEVICE /
+// GPRC_ERR_HIP.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gprc_internal.h"
+
+namespace gprc {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  g_last_error = std::string("HIP error '") + hipGetErrorString(e) + "' in " + what + " at " + file + ":" + std::to_string(line);
+  (void)hipGetLastError();
+  return e == hipErrorOutOfMemory ? GPRC_ERR_NOMEM : GPRC_ERR_HIP;
+}
+
+}  // namespace gprc
+
+using namespace gprc;
+
+struct gprc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int* info_dev = nullptr;     // LAPACK info written by the diagonal-block kernel
+  double* scal_dev = nullptr;  // 8 doubles of scalar results
+  size_t chunk_bytes = (size_t)16 << 30;  // budget for one K_star^T chunk
+};
+
+enum ModelType { MODEL_GPR = 1, MODEL_GPC = 2 };
+
+struct gprc_model {
+  gprc_ctx* ctx = nullptr;
+  int type = 0;
+  KernelSpec ks{};
+  int64_t n = 0, d = 0, n_pad = 0;
+  double* X = nullptr;       // d x n
+  double* y = nullptr;       // n_pad (zero padded)
+  double* packed = nullptr;  // factor, packed block columns
+  double* winv = nullptr;    // inverses of the 128x128 diagonal blocks
+  double* alpha = nullptr;   // n_pad (GPR) ; g = (y+1)/2 - P (GPC)
+  double* f_hat = nullptr;   // GPC
+  double* sw = nullptr;      // GPC sqrt(W)
+  double* work = nullptr;    // trsv partials
+  double logp = 0.0, noise = 0.0, logq = 0.0;
+};
+
+namespace {
+
+bool is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return attr.type == hipMemoryTypeDevice;
+}
+
+// Input staging: device pointers pass through, host arrays are copied to a temporary.
+struct In {
+  const double* dev = nullptr;
+  double* tmp = nullptr;
+  ~In() { if (tmp) (void)hipFree(tmp); }
+  int set(hipStream_t s, const double* p, int64_t count) {
+    if (count <= 0) { dev = nullptr; return 0; }
+    if (!p) { set_error("null input pointer"); return GPRC_ERR_ARG; }
+    if (is_device_ptr(p)) { dev = p; return 0; }
+    GPRC_HIP(hipMalloc(&tmp, sizeof(double) * (size_t)count));
+    GPRC_HIP(hipMemcpyAsync(tmp, p, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s));
+    dev = tmp;
+    return 0;
+  }
+};
+// Output staging: device pointers are written in place; host arrays get a temporary + D2H at finish().
+struct Out {
+  double* dev = nullptr;
+  double* tmp = nullptr;
+  double* host = nullptr;
+  int64_t count = 0;
+  ~Out() { if (tmp) (void)hipFree(tmp); }
+  int set(double* p, int64_t cnt) {
+    count = cnt;
+    if (cnt <= 0) return 0;
+    if (!p) { set_error("null output pointer"); return GPRC_ERR_ARG; }
+    if (is_device_ptr(p)) { dev = p; return 0; }
+    host = p;
+    GPRC_HIP(hipMalloc(&tmp, sizeof(double) * (size_t)cnt));
+    dev = tmp;
+    return 0;
+  }
+  int finish(hipStream_t s) {
+    if (host && count > 0) GPRC_HIP(hipMemcpyAsync(host, tmp, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
+    return 0;
+  }
+};
+
+struct DevMem {  // scoped device allocation
+  double* p = nullptr;
+  ~DevMem() { if (p) (void)hipFree(p); }
+  int alloc(int64_t count) {
+    if (count <= 0) count = 1;
+    GPRC_HIP(hipMalloc(&p, sizeof(double) * (size_t)count));
+    return 0;
+  }
+};
+
+int make_spec(int kernel, const double* params, int n_params, int64_t d, KernelSpec* ks) {
+  if (n_params < 0 || n_params > MAX_PARAMS || (n_params > 0 && !params)) { set_error("bad kernel parameter vector"); return GPRC_ERR_ARG; }
+  bool ok = false;
+  switch (kernel) {
+    case GPRC_CONSTANT: ok = n_params == 1; break;
+    case GPRC_LINEAR: ok = n_params == 1 || n_params == d; break;
+    case GPRC_POLYNOMIAL: case GPRC_GAMMAEXP: case GPRC_RATQUAD: ok = n_params == 2; break;
+    case GPRC_SQREXP: ok = n_params == 1; break;
+    default: set_error("unknown kernel id"); return GPRC_ERR_ARG;
+  }
+  if (!ok) { set_error("wrong number of kernel parameters for this kernel"); return GPRC_ERR_ARG; }
+  ks->id = kernel;
+  ks->n_params = n_params;
+  for (int i = 0; i < MAX_PARAMS; ++i) ks->p[i] = i < n_params ? params[i] : 0.0;
+  return 0;
+}
+
+int use_device(const gprc_ctx* ctx) {
+  if (!ctx) { set_error("null context"); return GPRC_ERR_ARG; }
+  GPRC_HIP(hipSetDevice(ctx->device));
+  return 0;
+}
+
+// ---- factorisation of all panels of a packed matrix (single GPU) ------------------------------
+int factor_panel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev) {
+  hipStream_t s = ctx->stream;
+  const int64_t ld = panel_ld(n_pad, p);
+  double* pan = packed + panel_offset(n_pad, p);
+  for (int j = 0; j < NB / NBI; ++j) {
+    const int64_t cj = (int64_t)j * NBI;
+    double* wblk = winv + (p * (NB / NBI) + j) * NBI * NBI;
+    GPRC_TRY(launch_potf2_inv(s, pan + cj + cj * ld, ld, wblk, info_dev, (int)(p * NB + cj)));
+    const int64_t below = ld - cj - NBI;
+    if (below <= 0) continue;
+    double* Lcol = pan + (cj + NBI) + cj * ld;
+    GPRC_TRY(launch_trsm_panel(s, Lcol, ld, below, wblk));
+    const int64_t rest = NB - cj - NBI;  // remaining columns of this panel
+    if (rest > 0) GPRC_TRY(launch_gemm_nt(s, pan + (cj + NBI) + (cj + NBI) * ld, ld, Lcol, ld, Lcol, ld, below, rest, NBI, 1));
+  }
+  return 0;
+}
+
+int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_host) {
+  hipStream_t s = ctx->stream;
+  const int64_t P = n_pad / NB;
+  GPRC_HIP(hipMemsetAsync(ctx->info_dev, 0, sizeof(int), s));
+  for (int64_t p = 0; p < P; ++p) {
+    GPRC_TRY(factor_panel(ctx, packed, n_pad, p, winv, ctx->info_dev));
+    if (p + 1 < P) GPRC_TRY(launch_trailing_update(s, packed, n_pad, p, p + 1, P, 1));
+  }
+  GPRC_HIP(hipMemcpyAsync(info_host, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+  GPRC_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// vt (m_pad x n_pad) := vt * L^-T
+int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt, int64_t m_pad) {
+  hipStream_t s = ctx->stream;
+  const int64_t P = n_pad / NB;
+  for (int64_t p = 0; p < P; ++p) {
+    const int64_t ld = panel_ld(n_pad, p);
+    const double* pan = packed + panel_offset(n_pad, p);
+    for (int j = 0; j < NB / NBI; ++j) {
+      const int64_t cj = p * NB + (int64_t)j * NBI;  // global column
+      const double* wblk = winv + (p * (NB / NBI) + j) * NBI * NBI;
+      GPRC_TRY(launch_trsm_panel(s, vt + cj * m_pad, m_pad, m_pad, wblk));
+      const int64_t rest = NB - (j + 1) * NBI;
+      if (rest > 0)
+        GPRC_TRY(launch_gemm_nt(s, vt + (cj + NBI) * m_pad, m_pad, vt + cj * m_pad, m_pad, pan + (j + 1) * NBI + (int64_t)j * NBI * ld, ld,
+                                m_pad, rest, NBI, 0));
+    }
+    const int64_t right = n_pad - (p + 1) * NB;
+    if (right > 0)
+      GPRC_TRY(launch_gemm_nt(s, vt + (p + 1) * NB * m_pad, m_pad, vt + p * NB * m_pad, m_pad, pan + NB, ld, m_pad, right, NB, 0));
+  }
+  return 0;
+}
+
+void free_model(gprc_model* m) {
+  if (!m) return;
+  if (m->ctx) (void)hipSetDevice(m->ctx->device);
+  for (double* p : {m->X, m->y, m->packed, m->winv, m->alpha, m->f_hat, m->sw, m->work})
+    if (p) (void)hipFree(p);
+  delete m;
+}
+
+int alloc_model(gprc_ctx* ctx, int type, const KernelSpec& ks, int64_t n, int64_t d, gprc_model** out) {
+  gprc_model* m = new (std::nothrow) gprc_model();
+  if (!m) { set_error("out of host memory"); return GPRC_ERR_NOMEM; }
+  m->ctx = ctx; m->type = type; m->ks = ks; m->n = n; m->d = d; m->n_pad = pad_up(n, NB);
+  const int64_t n_pad = m->n_pad;
+  int rc = 0;
+  auto A = [&](double** p, int64_t cnt) {
+    if (rc) return;
+    hipError_t e = hipMalloc(p, sizeof(double) * (size_t)cnt);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(model)", __FILE__, __LINE__);
+  };
+  A(&m->X, d * n);
+  A(&m->y, n_pad);
+  A(&m->packed, gprc_packed_size(n_pad));
+  A(&m->winv, gprc_winv_size(n_pad));
+  A(&m->alpha, n_pad);
+  A(&m->work, gprc_trsv_work_size(n_pad));
+  if (type == MODEL_GPC) { A(&m->f_hat, n_pad); A(&m->sw, n_pad); }
+  if (rc) { free_model(m); return rc; }
+  *out = m;
+  return 0;
+}
+
+int check_fit_args(gprc_ctx* ctx, const double* X, int64_t d, int64_t n, const double* y, gprc_model** out) {
+  if (!ctx || !X || !y || !out || d < 1 || n < 1) { set_error("fit: bad arguments"); return GPRC_ERR_ARG; }
+  return 0;
+}
+
+// one attempt; model must already hold X and y.  *info_out = LAPACK info.
+int gpr_attempt(gprc_model* m, double noise, int* info_out) {
+  gprc_ctx* ctx = m->ctx;
+  hipStream_t s = ctx->stream;
+  const int64_t n = m->n, n_pad = m->n_pad, P = n_pad / NB;
+  for (int64_t p = 0; p < P; ++p)
+    GPRC_TRY(launch_fill(s, m->ks, m->X, n, m->X, n, m->d, m->packed + panel_offset(n_pad, p), panel_ld(n_pad, p), p * NB,
+                         n_pad - p * NB, p * NB, NB, PAD_IDENTITY, noise));
+  GPRC_TRY(factor_all(ctx, m->packed, n_pad, m->winv, info_out));
+  if (*info_out != 0) return 0;
+  GPRC_HIP(hipMemcpyAsync(m->alpha, m->y, sizeof(double) * n_pad, hipMemcpyDeviceToDevice, s));
+  GPRC_TRY(launch_trsv(s, m->packed, m->winv, n_pad, m->alpha, 0, m->work));
+  GPRC_TRY(launch_trsv(s, m->packed, m->winv, n_pad, m->alpha, 1, m->work));
+  GPRC_TRY(launch_logp(s, m->packed, n_pad, n, m->y, m->alpha, ctx->scal_dev));
+  GPRC_HIP(hipMemcpyAsync(&m->logp, ctx->scal_dev, sizeof(double), hipMemcpyDeviceToHost, s));
+  GPRC_HIP(hipStreamSynchronize(s));
+  m->noise = noise;
+  return 0;
+}
+
+int gpr_prepare(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d, int64_t n,
+                const double* y, double noise, gprc_model** mout) {
+  GPRC_TRY(check_fit_args(ctx, X, d, n, y, mout));
+  if (!(noise >= 0.0)) { set_error("noise must be >= 0"); return GPRC_ERR_ARG; }  // R/GPRclass.R:130
+  GPRC_TRY(use_device(ctx));
+  KernelSpec ks;
+  GPRC_TRY(make_spec(kernel, params, n_params, d, &ks));
+  gprc_model* m = nullptr;
+  GPRC_TRY(alloc_model(ctx, MODEL_GPR, ks, n, d, &m));
+  hipStream_t s = ctx->stream;
+  hipError_t e = hipMemcpyAsync(m->X, X, sizeof(double) * d * n, hipMemcpyDefault, s);
+  if (e == hipSuccess) e = hipMemsetAsync(m->y, 0, sizeof(double) * m->n_pad, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(m->y, y, sizeof(double) * n, hipMemcpyDefault, s);
+  if (e != hipSuccess) { free_model(m); return hip_fail(e, "copy X,y", __FILE__, __LINE__); }
+  *mout = m;
+  return 0;
+}
+
+int chunk_rows(const gprc_ctx* ctx, int64_t n_pad, int64_t ns) {
+  int64_t rows = (int64_t)(ctx->chunk_bytes / (sizeof(double) * (size_t)n_pad)) / 128 * 128;
+  if (rows < 128) rows = 128;
+  const int64_t need = pad_up(ns, 128);
+  return (int)(rows < need ? rows : need);
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int gprc_abi_version(void) { return GPRC_ABI_VERSION; }
+const char* gprc_last_error(void) { return g_last_error.c_str(); }
+
+int gprc_device_count(int* count_out) {
+  if (!count_out) { set_error("null argument"); return GPRC_ERR_ARG; }
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { (void)hipGetLastError(); c = 0; }
+  *count_out = c;
+  return 0;
+}
+
+int gprc_ctx_create(int device, void* stream, gprc_ctx** ctx_out) {
+  if (!ctx_out) { set_error("null argument"); return GPRC_ERR_ARG; }
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device visible: the gprc native path needs an MI355X (gfx950); there is no CPU fallback");
+    return GPRC_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= c) { set_error("device index out of range"); return GPRC_ERR_ARG; }
+  GPRC_HIP(hipSetDevice(device));
+  gprc_ctx* ctx = new (std::nothrow) gprc_ctx();
+  if (!ctx) { set_error("out of host memory"); return GPRC_ERR_NOMEM; }
+  ctx->device = device;
+  if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+  else {
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+    ctx->own_stream = true;
+  }
+  hipError_t e = hipMalloc(&ctx->info_dev, 64);
+  if (e == hipSuccess) e = hipMalloc(&ctx->scal_dev, 64);
+  if (e != hipSuccess) { gprc_ctx_destroy(ctx); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
+  if (const char* cb = std::getenv("GPRC_CHUNK_BYTES")) {
+    const long long v = std::atoll(cb);
+    if (v > 0) ctx->chunk_bytes = (size_t)v;
+  }
+  *ctx_out = ctx;
+  return 0;
+}
+
+int gprc_ctx_destroy(gprc_ctx* ctx) {
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->info_dev) (void)hipFree(ctx->info_dev);
+  if (ctx->scal_dev) (void)hipFree(ctx->scal_dev);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return 0;
+}
+
+int gprc_ctx_synchronize(gprc_ctx* ctx) {
+  GPRC_TRY(use_device(ctx));
+  GPRC_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// ---- L1 -----------------------------------------------------------------------------------------
+int gprc_kernel_matrix(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* A, int64_t d,
+                       int64_t nA, const double* B, int64_t nB, double* out, int64_t ld_out) {
+  GPRC_TRY(use_device(ctx));
+  if (d < 1 || nA < 0 || nB < 0 || ld_out < nA) { set_error("kernel_matrix: bad dimensions"); return GPRC_ERR_ARG; }
+  if (nA == 0 || nB == 0) return 0;
+  KernelSpec ks;
+  GPRC_TRY(make_spec(kernel, params, n_params, d, &ks));
+  hipStream_t s = ctx->stream;
+  In a, b;
+  Out o;
+  GPRC_TRY(a.set(s, A, d * nA));
+  GPRC_TRY(b.set(s, B, d * nB));
+  GPRC_TRY(o.set(out, ld_out * nB));
+  for (int64_t c0 = 0; c0 < nB; c0 += 1 << 20) {  // grid.y limit
+    const int64_t nc = (nB - c0 < (1 << 20)) ? nB - c0 : (1 << 20);
+    GPRC_TRY(launch_fill(s, ks, a.dev, nA, b.dev, nB, d, o.dev + c0 * ld_out, ld_out, 0, nA, c0, nc, PAD_NONE, 0.0));
+  }
+  GPRC_TRY(o.finish(s));
+  GPRC_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int gprc_kernel_colwise(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* x,
+                        const double* y, int64_t d, int64_t m, double* out) {
+  GPRC_TRY(use_device(ctx));
+  if (d < 1 || m < 0) { set_error("kernel_colwise: bad dimensions"); return GPRC_ERR_ARG; }
+  if (m == 0) return 0;
+  KernelSpec ks;
+  GPRC_TRY(make_spec(kernel, params, n_params, d, &ks));
+  hipStream_t s = ctx->stream;
+  In a, b;
+  Out o;
+  GPRC_TRY(a.set(s, x, d * m));
+  GPRC_TRY(b.set(s, y, d * m));
+  GPRC_TRY(o.set(out, m));
+  GPRC_TRY(launch_colwise(s, ks, a.dev, b.dev, d, m, o.dev));
+  GPRC_TRY(o.finish(s));
+  GPRC_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ---- GPR ----------------------------------------------------------------------------------------
+int gprc_gpr_fit(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d,
+                 int64_t n, const double* y, double noise, gprc_model** model_out) {
+  gprc_model* m = nullptr;
+  GPRC_TRY(gpr_prepare(ctx, kernel, params, n_params, X, d, n, y, noise, &m));
+  int info = 0;
+  int rc = gpr_attempt(m, noise, &info);
+  if (rc != 0 || info != 0) {
+    free_model(m);
+    if (rc == 0) set_error("the leading minor of order " + std::to_string(info) + " is not positive definite");
+    return rc != 0 ? rc : info;
+  }
+  *model_out = m;
+  return 0;
+}
+
+int gprc_gpr_fit_retry(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d,
+                       int64_t n, const double* y, double noise, gprc_model** model_out, double* noise_used,
+                       int* attempts) {
+  gprc_model* m = nullptr;
+  GPRC_TRY(gpr_prepare(ctx, kernel, params, n_params, X, d, n, y, noise, &m));
+  double new_noise = noise;
+  for (int i = 1; i <= 10; ++i) {  // R/GPRclass.R:141-148
+    int info = 0;
+    int rc = gpr_attempt(m, new_noise, &info);
+    if (rc != 0) { free_model(m); return rc; }
+    if (info == 0) {
+      if (noise_used) *noise_used = new_noise;
+      if (attempts) *attempts = i;
+      *model_out = m;
+      return 0;
+    }
+    new_noise = 0.01 * i + noise;
+  }
+  free_model(m);
+  if (attempts) *attempts = 10;
+  set_error("Inputs lead to non positive definite covariance matrix. Try using a larger noise or a smaller lengthscale.");
+  return GPRC_ERR_NOT_PD;
+}
+
+int gprc_gpr_predict(gprc_model* m, const double* X_star, int64_t ns, int pointwise, double* mean_out, double* var_out) {
+  if (!m || m->type != MODEL_GPR) { set_error("predict: not a GPR model"); return GPRC_ERR_ARG; }
+  if (ns < 0 || (ns > 0 && (!X_star || !mean_out || !var_out))) { set_error("predict: bad arguments"); return GPRC_ERR_ARG; }
+  if (ns == 0) return 0;
+  gprc_ctx* ctx = m->ctx;
+  GPRC_TRY(use_device(ctx));
+  hipStream_t s = ctx->stream;
+  const int64_t n = m->n, n_pad = m->n_pad, d = m->d;
+  In xs;
+  Out mean, var;
+  GPRC_TRY(xs.set(s, X_star, d * ns));
+  GPRC_TRY(mean.set(mean_out, ns));
+  GPRC_TRY(var.set(var_out, pointwise ? ns : ns * ns));
+
+  const int64_t rows = pointwise ? chunk_rows(ctx, n_pad, ns) : pad_up(ns, 128);
+  DevMem vt, red, tmp;
+  GPRC_TRY(vt.alloc(rows * n_pad));
+  GPRC_TRY(red.alloc(rows * rowreduce_splits(n_pad)));
+  GPRC_TRY(tmp.alloc(3 * rows));
+  double* mean_c = tmp.p;
+  double* ss_c = tmp.p + rows;
+  double* kss_c = tmp.p + 2 * rows;
+
+  if (pointwise) {
+    for (int64_t s0 = 0; s0 < ns; s0 += rows) {
+      const int64_t mcur = (ns - s0 < rows) ? ns - s0 : rows;
+      const int64_t m_pad = pad_up(mcur, 128);
+      const double* xc = xs.dev + s0 * d;
+      GPRC_TRY(launch_fill(s, m->ks, xc, mcur, m->X, n, d, vt.p, m_pad, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0));  // K_star^T  :160
+      GPRC_TRY(launch_row_reduce(s, vt.p, m_pad, m_pad, n_pad, m->alpha, mean_c, red.p));                      // :161
+      GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt.p, m_pad));                                        // :162
+      GPRC_TRY(launch_row_reduce(s, vt.p, m_pad, m_pad, n_pad, nullptr, ss_c, red.p));                          // colSums(v*v)
+      GPRC_TRY(launch_colwise(s, m->ks, xc, xc, d, mcur, kss_c));                                               // k(X*,X*)  :164
+      GPRC_TRY(launch_sub(s, kss_c, ss_c, var.dev + s0, mcur));
+      GPRC_HIP(hipMemcpyAsync(mean.dev + s0, mean_c, sizeof(double) * mcur, hipMemcpyDeviceToDevice, s));
+    }
+  } else {
+    const int64_t m_pad = rows;
+    DevMem cov;
+    GPRC_TRY(cov.alloc(m_pad * m_pad));
+    GPRC_TRY(launch_fill(s, m->ks, xs.dev, ns, m->X, n, d, vt.p, m_pad, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0));
+    GPRC_TRY(launch_row_reduce(s, vt.p, m_pad, m_pad, n_pad, m->alpha, mean_c, red.p));
+    GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt.p, m_pad));
+    GPRC_TRY(launch_fill(s, m->ks, xs.dev, ns, xs.dev, ns, d, cov.p, m_pad, 0, m_pad, 0, m_pad, PAD_ZERO, 0.0));  // :167
+    GPRC_TRY(launch_gemm_nt(s, cov.p, m_pad, vt.p, m_pad, vt.p, m_pad, m_pad, m_pad, n_pad, 0));                  // - t(v) %*% v
+    GPRC_HIP(hipMemcpy2DAsync(var.dev, sizeof(double) * ns, cov.p, sizeof(double) * m_pad, sizeof(double) * ns, ns,
+                              hipMemcpyDeviceToDevice, s));
+    GPRC_HIP(hipMemcpyAsync(mean.dev, mean_c, sizeof(double) * ns, hipMemcpyDeviceToDevice, s));
+    GPRC_HIP(hipStreamSynchronize(s));  // cov goes out of scope
+  }
+  GPRC_TRY(mean.finish(s));
+  GPRC_TRY(var.finish(s));
+  GPRC_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int gprc_model_dims(const gprc_model* m, int64_t* n_out, int64_t* d_out) {
+  if (!m) { set_error("null model"); return GPRC_ERR_ARG; }
+  if (n_out) *n_out = m->n;
+  if (d_out) *d_out = m->d;
+  return 0;
+}
+
+int gprc_model_get_L(gprc_model* m, double* L_out, int64_t ld_out) {
+  if (!m || !L_out || ld_out < m->n) { set_error("get_L: bad arguments"); return GPRC_ERR_ARG; }
+  GPRC_TRY(use_device(m->ctx));
+  hipStream_t s = m->ctx->stream;
+  Out o;
+  GPRC_TRY(o.set(L_out, ld_out * m->n));
+  if (o.host && ld_out != m->n) GPRC_HIP(hipMemsetAsync(o.dev, 0, sizeof(double) * ld_out * m->n, s));
+  GPRC_TRY(launch_unpack_L(s, m->packed, m->n_pad, m->n, o.dev, ld_out));
+  GPRC_TRY(o.finish(s));
+  GPRC_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+static int copy_out_vec(gprc_model* m, const double* src, double* dst, int64_t cnt) {
+  if (!m || !dst || !src) { set_error("bad arguments"); return GPRC_ERR_ARG; }
+  GPRC_TRY(use_device(m->ctx));
+  GPRC_HIP(hipMemcpyAsync(dst, src, sizeof(double) * cnt, hipMemcpyDefault, m->ctx->stream));
+  GPRC_HIP(hipStreamSynchronize(m->ctx->stream));
+  return 0;
+}
+
+int gprc_gpr_get_alpha(gprc_model* m, double* alpha_out) {
+  if (!m || m->type != MODEL_GPR) { set_error("not a GPR model"); return GPRC_ERR_ARG; }
+  return copy_out_vec(m, m->alpha, alpha_out, m->n);
+}
+int gprc_gpr_get_logp(gprc_model* m, double* logp_out) {
+  if (!m || m->type != MODEL_GPR || !logp_out) { set_error("not a GPR model"); return GPRC_ERR_ARG; }
+  *logp_out = m->logp;
+  return 0;
+}
+int gprc_gpr_get_noise(gprc_model* m, double* noise_out) {
+  if (!m || m->type != MODEL_GPR || !noise_out) { set_error("not a GPR model"); return GPRC_ERR_ARG; }
+  *noise_out = m->noise;
+  return 0;
+}
+int gprc_model_free(gprc_model* m) {
+  if (m && m->ctx && m->ctx->stream) (void)hipStreamSynchronize(m->ctx->stream);
+  free_model(m);
+  return 0;
+}
+
+// ---- GPC ----------------------------------------------------------------------------------------
+int gprc_gpc_fit(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d,
+                 int64_t n, const double* y, double epsilon, int max_iter, gprc_model** model_out, int* iters_out) {
+  GPRC_TRY(check_fit_args(ctx, X, d, n, y, model_out));
+  if (!(epsilon > 0.0)) { set_error("epsilon must be > 0"); return GPRC_ERR_ARG; }  // R/GPCclass.R:68
+  if (max_iter <= 0) max_iter = 1000;
+  GPRC_TRY(use_device(ctx));
+  KernelSpec ks;
+  GPRC_TRY(make_spec(kernel, params, n_params, d, &ks));
+  gprc_model* m = nullptr;
+  GPRC_TRY(alloc_model(ctx, MODEL_GPC, ks, n, d, &m));
+  hipStream_t s = ctx->stream;
+  const int64_t n_pad = m->n_pad;
+  DevMem Kf, vec, red;
+  int rc = 0;
+#define GPC_TRY(call) do { rc = (call); if (rc != 0) { free_model(m); return rc; } } while (0)
+#define GPC_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { free_model(m); return hip_fail(e__, #call, __FILE__, __LINE__); } } while (0)
+  GPC_TRY(Kf.alloc(n_pad * n_pad));
+  GPC_TRY(vec.alloc(4 * n_pad));
+  GPC_TRY(red.alloc(n_pad * rowreduce_splits(n_pad)));
+  double *b = vec.p, *t = vec.p + n_pad, *a = vec.p + 2 * n_pad, *f = m->f_hat;
+  GPC_HIP(hipMemcpyAsync(m->X, X, sizeof(double) * d * n, hipMemcpyDefault, s));
+  GPC_HIP(hipMemsetAsync(m->y, 0, sizeof(double) * n_pad, s));
+  GPC_HIP(hipMemcpyAsync(m->y, y, sizeof(double) * n, hipMemcpyDefault, s));
+  GPC_HIP(hipMemsetAsync(f, 0, sizeof(double) * n_pad, s));  // f <- rep(0, n)  R/GPCclass.R:74
+  GPC_HIP(hipMemsetAsync(vec.p, 0, sizeof(double) * 4 * n_pad, s));
+  for (int64_t c0 = 0; c0 < n_pad; c0 += 32768) {  // K <- covariance_matrix(X, X, k)  :73 (dense, zero padded)
+    const int64_t nc = (n_pad - c0 < 32768) ? n_pad - c0 : 32768;
+    GPC_TRY(launch_fill(s, ks, m->X, n, m->X, n, d, Kf.p + c0 * n_pad, n_pad, 0, n_pad, c0, nc, PAD_ZERO, 0.0));
+  }
+  int it = 0;
+  double objective = 0.0, last_objective = 0.0, least_objective = 0.0;
+  int status = 0;
+  for (;;) {
+    ++it;
+    GPC_TRY(launch_gpc_pre(s, f, m->y, n, m->sw, b));                       // :78-81
+    GPC_TRY(launch_gpc_build_B(s, Kf.p, n_pad, m->sw, m->packed));           // :80
+    int info = 0;
+    GPC_TRY(factor_all(ctx, m->packed, n_pad, m->winv, &info));
+    if (info != 0) { free_model(m); set_error("GPC: I + sqrt(W) K sqrt(W) not positive definite"); return info; }
+    GPC_TRY(launch_row_reduce(s, Kf.p, n_pad, n_pad, n_pad, b, t, red.p));  // K %*% b
+    GPC_TRY(launch_gpc_scale(s, m->sw, t, t, n_pad));                        // sqrt(W) * .
+    GPC_TRY(launch_trsv(s, m->packed, m->winv, n_pad, t, 0, m->work));       // :82
+    GPC_TRY(launch_trsv(s, m->packed, m->winv, n_pad, t, 1, m->work));       // :83
+    GPC_TRY(launch_gpc_a(s, b, m->sw, t, a, n_pad));                         // :84
+    GPC_TRY(launch_row_reduce(s, Kf.p, n_pad, n_pad, n_pad, a, f, red.p));  // f <- K %*% a  :85
+    GPC_TRY(launch_gpc_objective(s, a, f, m->y, n, ctx->scal_dev));          // :86
+    GPC_HIP(hipMemcpyAsync(&objective, ctx->scal_dev, sizeof(double), hipMemcpyDeviceToHost, s));
+    GPC_HIP(hipStreamSynchronize(s));
+    if (it > 1) {
+      if (std::fabs(objective - last_objective) < epsilon) break;                          // :88
+      else if (least_objective + 10.0 < objective) { status = GPRC_ERR_DIVERGED; break; }  // :90
+    } else {
+      least_objective = objective;
+    }
+    last_objective = objective;
+    if (it >= max_iter) { status = GPRC_ERR_MAXITER; break; }
+  }
+  if (iters_out) *iters_out = it;
+  if (status != 0) {
+    free_model(m);
+    set_error(status == GPRC_ERR_DIVERGED ? "Apparently does not converge." : "GPC: iteration cap reached");
+    return status;
+  }
+  // final L from the converged f (:99-102), logq = objective - sum(diag(L)) (:103, sic)
+  GPC_TRY(launch_gpc_pre(s, f, m->y, n, m->sw, b));
+  GPC_TRY(launch_gpc_build_B(s, Kf.p, n_pad, m->sw, m->packed));
+  int info = 0;
+  GPC_TRY(factor_all(ctx, m->packed, n_pad, m->winv, &info));
+  if (info != 0) { free_model(m); set_error("GPC: final factorisation failed"); return info; }
+  double dsum = 0.0;
+  GPC_TRY(launch_diag_sum(s, m->packed, n_pad, n, ctx->scal_dev));
+  GPC_HIP(hipMemcpyAsync(&dsum, ctx->scal_dev, sizeof(double), hipMemcpyDeviceToHost, s));
+  GPC_TRY(launch_gpc_grad(s, f, m->y, n, m->alpha, m->sw));  // g = (y+1)/2 - P, sw = sqrt(P(1-P)) for predict
+  GPC_HIP(hipStreamSynchronize(s));
+  m->logq = objective - dsum;
+#undef GPC_TRY
+#undef GPC_HIP
+  *model_out = m;
+  return 0;
+}
+
+int gprc_gpc_predict_latent(gprc_model* m, const double* X_star, int64_t ns, double* fs_bar_out, double* Vfs_out) {
+  if (!m || m->type != MODEL_GPC) { set_error("predict_latent: not a GPC model"); return GPRC_ERR_ARG; }
+  if (ns < 0 || (ns > 0 && (!X_star || !fs_bar_out || !Vfs_out))) { set_error("predict_latent: bad arguments"); return GPRC_ERR_ARG; }
+  if (ns == 0) return 0;
+  gprc_ctx* ctx = m->ctx;
+  GPRC_TRY(use_device(ctx));
+  hipStream_t s = ctx->stream;
+  const int64_t n = m->n, n_pad = m->n_pad, d = m->d;
+  In xs;
+  Out fs, vf;
+  GPRC_TRY(xs.set(s, X_star, d * ns));
+  GPRC_TRY(fs.set(fs_bar_out, ns));
+  GPRC_TRY(vf.set(Vfs_out, ns));
+  const int64_t rows = chunk_rows(ctx, n_pad, ns);
+  DevMem vt, red, tmp;
+  GPRC_TRY(vt.alloc(rows * n_pad));
+  GPRC_TRY(red.alloc(rows * rowreduce_splits(n_pad)));
+  GPRC_TRY(tmp.alloc(3 * rows));
+  double *mean_c = tmp.p, *ss_c = tmp.p + rows, *kss_c = tmp.p + 2 * rows;
+  for (int64_t s0 = 0; s0 < ns; s0 += rows) {
+    const int64_t mcur = (ns - s0 < rows) ? ns - s0 : rows;
+    const int64_t m_pad = pad_up(mcur, 128);
+    const double* xc = xs.dev + s0 * d;
+    GPRC_TRY(launch_fill(s, m->ks, xc, mcur, m->X, n, d, vt.p, m_pad, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0));  // R/GPCclass.R:112
+    GPRC_TRY(launch_row_reduce(s, vt.p, m_pad, m_pad, n_pad, m->alpha, mean_c, red.p));                      // :113
+    GPRC_TRY(launch_scale_cols(s, vt.p, m_pad, m_pad, n_pad, m->sw));                                         // sqrt(W) * K_star
+    GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt.p, m_pad));                                        // :114
+    GPRC_TRY(launch_row_reduce(s, vt.p, m_pad, m_pad, n_pad, nullptr, ss_c, red.p));
+    GPRC_TRY(launch_colwise(s, m->ks, xc, xc, d, mcur, kss_c));
+    GPRC_TRY(launch_sub(s, kss_c, ss_c, vf.dev + s0, mcur));                                                  // :115
+    GPRC_HIP(hipMemcpyAsync(fs.dev + s0, mean_c, sizeof(double) * mcur, hipMemcpyDeviceToDevice, s));
+  }
+  GPRC_TRY(fs.finish(s));
+  GPRC_TRY(vf.finish(s));
+  GPRC_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int gprc_gpc_get_f_hat(gprc_model* m, double* f_hat_out) {
+  if (!m || m->type != MODEL_GPC) { set_error("not a GPC model"); return GPRC_ERR_ARG; }
+  return copy_out_vec(m, m->f_hat, f_hat_out, m->n);
+}
+int gprc_gpc_get_logq(gprc_model* m, double* logq_out) {
+  if (!m || m->type != MODEL_GPC || !logq_out) { set_error("not a GPC model"); return GPRC_ERR_ARG; }
+  *logq_out = m->logq;
+  return 0;
+}
+
+// ---- layout helpers + device-level building blocks ------------------------------------------------
+int64_t gprc_panel_width(void) { return NB; }
+int64_t gprc_pad(int64_t n) { return pad_up(n, NB); }
+int64_t gprc_panel_count(int64_t n_pad) { return n_pad / NB; }
+int64_t gprc_panel_offset(int64_t n_pad, int64_t p) { return panel_offset(n_pad, p); }
+int64_t gprc_panel_elems(int64_t n_pad, int64_t p) { return panel_ld(n_pad, p) * NB; }
+int64_t gprc_packed_size(int64_t n_pad) { return panel_offset(n_pad, n_pad / NB); }
+int64_t gprc_winv_size(int64_t n_pad) { return n_pad * NBI; }
+int64_t gprc_trsv_work_size(int64_t n_pad) { return (n_pad / 1024 + 2) * 128; }
+int64_t gprc_rowreduce_splits(int64_t cols) { return rowreduce_splits(cols); }
+
+int gprc_dev_fill_panel(gprc_ctx* ctx, int kernel, const double* params_host, int n_params, const double* X,
+                        int64_t d, int64_t n, int64_t n_pad, double noise, double* packed, int64_t p) {
+  GPRC_TRY(use_device(ctx));
+  if (n_pad != pad_up(n, NB) || p < 0 || p >= n_pad / NB) { set_error("fill_panel: bad layout arguments"); return GPRC_ERR_ARG; }
+  KernelSpec ks;
+  GPRC_TRY(make_spec(kernel, params_host, n_params, d, &ks));
+  return launch_fill(ctx->stream, ks, X, n, X, n, d, packed + panel_offset(n_pad, p), panel_ld(n_pad, p), p * NB, n_pad - p * NB,
+                     p * NB, NB, PAD_IDENTITY, noise);
+}
+
+int gprc_dev_factor_panel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev) {
+  GPRC_TRY(use_device(ctx));
+  if (n_pad % NB || p < 0 || p >= n_pad / NB || !info_dev) { set_error("factor_panel: bad arguments"); return GPRC_ERR_ARG; }
+  return factor_panel(ctx, packed, n_pad, p, winv, info_dev);
+}
+
+int gprc_dev_update_trailing(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, int64_t q_begin,
+                             int64_t q_end, int64_t q_stride) {
+  GPRC_TRY(use_device(ctx));
+  if (n_pad % NB) { set_error("update_trailing: bad n_pad"); return GPRC_ERR_ARG; }
+  if (q_begin >= q_end) return 0;
+  return launch_trailing_update(ctx->stream, packed, n_pad, p, q_begin, q_end, q_stride);
+}
+
+int gprc_dev_trsv(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose,
+                  double* work) {
+  GPRC_TRY(use_device(ctx));
+  return launch_trsv(ctx->stream, packed, winv, n_pad, b, transpose, work);
+}
+
+int gprc_dev_fill_cross(gprc_ctx* ctx, int kernel, const double* params_host, int n_params, const double* X_star,
+                        int64_t d, int64_t m, int64_t m_pad, const double* X, int64_t n, int64_t n_pad, double* vt) {
+  GPRC_TRY(use_device(ctx));
+  if (m_pad % 128 || m_pad < m || n_pad < n) { set_error("fill_cross: bad padding"); return GPRC_ERR_ARG; }
+  KernelSpec ks;
+  GPRC_TRY(make_spec(kernel, params_host, n_params, d, &ks));
+  return launch_fill(ctx->stream, ks, X_star, m, X, n, d, vt, m_pad, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0);
+}
+
+int gprc_dev_row_reduce(gprc_ctx* ctx, const double* vt, int64_t ld, int64_t rows, int64_t cols, const double* w,
+                        double* out, double* work) {
+  GPRC_TRY(use_device(ctx));
+  return launch_row_reduce(ctx->stream, vt, ld, rows, cols, w, out, work);
+}
+
+int gprc_dev_solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt,
+                        int64_t m_pad) {
+  GPRC_TRY(use_device(ctx));
+  if (m_pad % 128 || n_pad % NB) { set_error("solve_rows: bad padding"); return GPRC_ERR_ARG; }
+  return solve_rows(ctx, packed, winv, n_pad, vt, m_pad);
+}
+
+}  // extern "C"

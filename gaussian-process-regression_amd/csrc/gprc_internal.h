@@ -1,0 +1,88 @@
+// gprc_internal.h -- shared declarations of the gfx950 implementation behind include/gprc_native.h.
+// Host-side launchers live next to their kernels; the C ABI (gprc_api.hip) only composes them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/gprc_native.h"
+
+namespace gprc {
+
+// ---- geometry (DESIGN.md "Data layout") -------------------------------------------------------
+constexpr int NB = 512;   // outer panel width: K-depth of the trailing update (64 flop/B of C traffic)
+constexpr int NBI = 128;  // inner block: one LDS-resident diagonal factorisation, one GEMM tile edge
+constexpr int MAX_PARAMS = 64;
+
+__host__ __device__ static inline int64_t pad_up(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
+__host__ __device__ static inline int64_t panel_offset(int64_t n_pad, int64_t p) { return (int64_t)NB * (p * n_pad - (int64_t)NB * p * (p - 1) / 2); }
+__host__ __device__ static inline int64_t panel_ld(int64_t n_pad, int64_t p) { return n_pad - p * NB; }
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define GPRC_HIP(call)                                                          \
+  do {                                                                          \
+    hipError_t e__ = (call);                                                    \
+    if (e__ != hipSuccess) return ::gprc::hip_fail(e__, #call, __FILE__, __LINE__); \
+  } while (0)
+#define GPRC_TRY(call)          \
+  do {                          \
+    int rc__ = (call);          \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+#define GPRC_LAUNCH_CHECK() GPRC_HIP(hipGetLastError())
+
+struct KernelSpec {
+  int id;
+  int n_params;
+  double p[MAX_PARAMS];
+};
+
+// how the out-of-range part of a fill is written
+enum PadMode { PAD_NONE = 0,      // exact extents, bounds-checked stores (user-facing covariance_matrix)
+               PAD_IDENTITY = 1,  // symmetric K + noise*I, identity outside n (the factor's padding)
+               PAD_ZERO = 2 };    // zero outside the valid extents (cross-covariance chunks)
+
+// ---- launchers (kernels_fill.hip) --------------------------------------------------------------
+// out[(i-row0) + (j-col0)*ld] = k(A_i, B_j) for i in [row0,row0+nrows), j in [col0,col0+ncols)
+int launch_fill(hipStream_t s, const KernelSpec& ks, const double* A, int64_t nA, const double* B, int64_t nB, int64_t d,
+                double* out, int64_t ld, int64_t row0, int64_t nrows, int64_t col0, int64_t ncols, PadMode mode,
+                double noise);
+int launch_colwise(hipStream_t s, const KernelSpec& ks, const double* x, const double* y, int64_t d, int64_t m, double* out);
+
+// ---- launchers (kernels_chol.hip) --------------------------------------------------------------
+// factor the 128x128 diagonal block at A (ld) in LDS, write L in place and its inverse to winv
+int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* info_dev, int col0);
+// X[M x 128] := X * W^T for lower-triangular 128x128 W (= inverse of a diagonal block of L)
+int launch_trsm_panel(hipStream_t s, double* X, int64_t ldx, int64_t M, const double* winv);
+// C[M x N] -= A[M x K] * B[N x K]^T; lower_diag >= 0: row tile r / col tile c with r + lower_diag < c is skipped
+int launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
+                   int64_t M, int64_t N, int64_t K, int lower);
+// trailing update of packed panels q_begin, q_begin+q_stride, ... < q_end with factored panel p
+int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t p, int64_t q_begin, int64_t q_end,
+                           int64_t q_stride);
+
+// ---- launchers (kernels_vec.hip) ---------------------------------------------------------------
+int launch_trsv(hipStream_t s, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose, double* work);
+int64_t rowreduce_splits(int64_t cols);
+int launch_row_reduce(hipStream_t s, const double* vt, int64_t ld, int64_t rows, int64_t cols, const double* w, double* out,
+                      double* work);
+// out[0] = -0.5*y.alpha - sum(log(diag L)) - n/2 log(2 pi)   (R/GPRclass.R:153); n valid entries
+int launch_logp(hipStream_t s, const double* packed, int64_t n_pad, int64_t n, const double* y, const double* alpha, double* out);
+// unpack the factor into a dense n x n lower matrix (upper = 0)
+int launch_unpack_L(hipStream_t s, const double* packed, int64_t n_pad, int64_t n, double* out, int64_t ld_out);
+// out[i] = kss[i] - ss[i]
+int launch_sub(hipStream_t s, const double* a, const double* b, double* out, int64_t n);
+// GPC vector stages (R/GPCclass.R:78-86, 99-103, 110-114)
+int launch_gpc_pre(hipStream_t s, const double* f, const double* y, int64_t n, double* sw, double* b);
+int launch_gpc_scale(hipStream_t s, const double* sw, const double* v, double* out, int64_t n);                   // out = sw*v
+int launch_gpc_a(hipStream_t s, const double* b, const double* sw, const double* t, double* a, int64_t n);        // a = b - sw*t
+int launch_gpc_objective(hipStream_t s, const double* a, const double* f, const double* y, int64_t n, double* out);
+int launch_gpc_build_B(hipStream_t s, const double* Kfull, int64_t n_pad, const double* sw, double* packed);
+int launch_gpc_grad(hipStream_t s, const double* f, const double* y, int64_t n, double* g, double* sw);           // g=(y+1)/2-P
+int launch_scale_cols(hipStream_t s, double* vt, int64_t ld, int64_t rows, int64_t cols, const double* colscale); // vt[i,j]*=colscale[j]
+int launch_diag_sum(hipStream_t s, const double* packed, int64_t n_pad, int64_t n, double* out);                  // sum(diag(L))
+
+}  // namespace gprc

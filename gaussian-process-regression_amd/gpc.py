@@ -1,0 +1,109 @@
+"""GPC: host mirror of the reference's R6 class `GPC` (R/GPCclass.R:55-210).
+
+`GPC$new(X, y, k, epsilon)` runs the Laplace/IRLS mode search on the GPU (kernel fill once, then per
+iteration B = I + sqrt(W) K sqrt(W), its Cholesky, two triangular solves and two K-matvecs);
+`predict_class` gets fs_bar / Vfs from the GPU (R/GPCclass.R:109-115) and then evaluates the
+reference's per-point 1-D integral (:116-117) on the host with QUADPACK, as the reference does with
+stats::integrate -- that integral is the caller of the hot path, not part of it.
+Reference quirks are reproduced: logq uses sum(diag(L)) (:103), and the integral passes the
+*variance* Vfs as dnorm's sd (:117).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+
+import numpy as np
+
+from . import _native as nat
+from .covfunc import as_points, require_tagged
+from .gpr import _ReadOnly, _is_numeric_vector
+
+__all__ = ["GPC"]
+
+
+class GPC:
+    """GPC$new(X, y, k, epsilon = 1e-5)  --  R/GPCclass.R:66."""
+
+    def __init__(self, X, y, k, epsilon=1e-5, *, ctx=None, max_iter=0):
+        Xa = np.asarray(X)
+        if Xa.dtype.kind not in "fiub" or not _is_numeric_vector(y):
+            raise TypeError("is.numeric(X), is.vector(y), is.numeric(y) are not all TRUE")        # :67
+        if not isinstance(epsilon, (int, float, np.floating, np.integer)) or not epsilon > 0 or not callable(k):
+            raise TypeError("is.numeric(epsilon), epsilon > 0, is.function(k) are not all TRUE")  # :68
+        Xm = as_points(Xa)                                                                       # :70
+        y = np.ascontiguousarray(np.asarray(y, dtype=np.float64))
+        if y.size != Xm.shape[1]:
+            raise ValueError("length(y) == ncol(X) is not TRUE")                                 # :71
+        k = require_tagged(k, "GPC")
+        d, n = Xm.shape
+        self._ctx = ctx or nat.default_context()
+        self._X, self._y, self._k = Xm, y, k
+        self._L = None
+        self._model = C.c_void_p()
+        _, pp, npar = nat.params_array(k.native_params(d))
+        iters = C.c_int()
+        rc = nat.lib().gprc_gpc_fit(self._ctx.handle, k.gprc_kernel[0], pp, npar, Xm.ctypes.data, d, n, y.ctypes.data,
+                                    float(epsilon), int(max_iter), C.byref(self._model), C.byref(iters))
+        if rc == nat.ERR_DIVERGED:
+            raise ArithmeticError("Apparently does not converge.")                               # :91
+        nat.check(rc)
+        self.iterations = iters.value
+        sys.stderr.write(f"Convergence after {iters.value} iterations\n")                        # :98 message()
+        f_hat = np.empty(n)
+        nat.check(nat.lib().gprc_gpc_get_f_hat(self._model, f_hat.ctypes.data))
+        lq = C.c_double()
+        nat.check(nat.lib().gprc_gpc_get_logq(self._model, C.byref(lq)))
+        self._f_hat, self._logq = f_hat, lq.value
+
+    @classmethod
+    def new(cls, *args, **kwargs):
+        return cls(*args, **kwargs)
+
+    def predict_latent(self, X_star):
+        """fs_bar and Vfs of R/GPCclass.R:109-115 (the GPU part of predict_class)."""
+        Xs = np.asarray(X_star, dtype=np.float64)
+        Xs = as_points(Xs) if Xs.ndim <= 1 else as_points(Xs)                                    # :109
+        if Xs.shape[0] != self._X.shape[0]:
+            raise ValueError("X_star must have nrow(X) rows")
+        ns = Xs.shape[1]
+        fs, vf = np.empty(ns), np.empty(ns)
+        nat.check(nat.lib().gprc_gpc_predict_latent(self._model, Xs.ctypes.data, ns, fs.ctypes.data, vf.ctypes.data))
+        return fs, vf
+
+    def predict_class(self, X_star):
+        """GPC$predict_class(X_star)  --  R/GPCclass.R:108-118: P(y* = +1 | x*) per test point."""
+        from scipy import integrate, stats
+        fs, vf = self.predict_latent(X_star)
+        out = np.empty(fs.size)
+        for i in range(fs.size):  # :116-117, sd = Vfs[i] (sic)
+            mu, sd = fs[i], vf[i]
+            out[i] = integrate.quad(lambda z: (1.0 / (1.0 + np.exp(-z))) * stats.norm.pdf(z, loc=mu, scale=sd),
+                                    -np.inf, np.inf)[0]
+        return out
+
+    def _get_L(self):
+        if self._L is None:
+            n = self._X.shape[1]
+            L = np.empty((n, n), order="F")
+            nat.check(nat.lib().gprc_model_get_L(self._model, L.ctypes.data, n))
+            self._L = L
+        return self._L
+
+    X = _ReadOnly("X", lambda s: s._X)
+    k = _ReadOnly("k", lambda s: s._k)
+    y = _ReadOnly("y", lambda s: s._y)
+    f_hat = _ReadOnly("f_hat", lambda s: s._f_hat)
+    L = _ReadOnly("L", _get_L)
+    logq = _ReadOnly("logq", lambda s: s._logq)
+
+    def close(self):
+        if getattr(self, "_model", None):
+            nat.lib().gprc_model_free(self._model)
+            self._model = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,215 @@
+"""GPR: host mirror of the reference's R6 class `GPR` and its six kernel subclasses
+(R/GPRclass.R:116-351).  Construction = kernel fill + Cholesky + alpha + logp on the GPU
+(`GPR$initialize`, :127-154); `predict` = `GPR$predict` (:155-170).  Same argument names, orders,
+defaults, return shapes, warnings and error texts; the plot methods (:171-228) are rendering code and
+stay with the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _native as nat
+from .covfunc import (as_points, cov_func, constant, linear, polynomial, sqrexp, gammaexp, rationalquadratic,
+                      require_tagged)
+
+__all__ = ["GPR", "GPR_constant", "GPR_linear", "GPR_polynomial", "GPR_sqrexp", "GPR_gammaexp", "GPR_rationalquadratic"]
+
+
+def _r_num(x) -> str:
+    """sprintf("%s", <double>) as R prints it (15 significant digits)."""
+    return f"{float(x):.15g}"
+
+
+def _is_numeric_vector(y):
+    y = np.asarray(y)
+    return y.ndim == 1 and y.dtype.kind in "fiub"
+
+
+class _ReadOnly:
+    """Active binding: readable, `stop("`$name` is read only")` on assignment (R/GPRclass.R:230-280)."""
+
+    def __init__(self, name, getter):
+        self.name, self.getter = name, getter
+
+    def __get__(self, obj, objtype=None):
+        return self if obj is None else self.getter(obj)
+
+    def __set__(self, obj, value):
+        raise AttributeError(f"`${self.name}` is read only")
+
+
+class GPR:
+    """GPR$new(X, y, noise = 0, k, cov_names)  --  R/GPRclass.R:127-128."""
+
+    def __init__(self, X, y, noise=0, k=None, cov_names=None, *, ctx=None):
+        if k is None:
+            # the reference default is k = fit(X, y, noise, cov_names)$func (R/GPRclass.R:127); fit() is the
+            # first "next" row of the scope table and is not on this hot path yet.
+            raise NotImplementedError("GPR: pass k = cov_func(...); the default k = fit(...)$func is not part of the "
+                                      "MI355X hot path yet")
+        Xa = np.asarray(X)
+        if Xa.dtype.kind not in "fiub" or not _is_numeric_vector(y):
+            raise TypeError("is.numeric(X), is.vector(y), is.numeric(y) are not all TRUE")   # :129
+        if np.ndim(noise) != 0 or not isinstance(noise, (int, float, np.floating, np.integer)) or not noise >= 0:
+            raise ValueError("is.numeric(noise), length(noise) == 1, noise >= 0 are not all TRUE")  # :130
+        Xm = as_points(Xa)                                                                  # :132
+        y = np.ascontiguousarray(np.asarray(y, dtype=np.float64))
+        if y.size != Xm.shape[1]:
+            raise ValueError("length(y) == ncol(X) is not TRUE")                            # :133
+        k = require_tagged(k, "GPR")
+        d, n = Xm.shape
+        self._ctx = ctx or nat.default_context()
+        self._X, self._y, self._k = Xm, y, k
+        self._L = None
+        self._model = C.c_void_p()
+        _, pp, npar = nat.params_array(k.native_params(d))
+        noise_used, attempts = C.c_double(), C.c_int()
+        rc = nat.lib().gprc_gpr_fit_retry(self._ctx.handle, k.gprc_kernel[0], pp, npar, Xm.ctypes.data, d, n, y.ctypes.data,
+                                          float(noise), C.byref(self._model), C.byref(noise_used), C.byref(attempts))
+        if rc == nat.ERR_NOT_PD:
+            raise ArithmeticError("Inputs lead to non positive definite covariance matrix. "
+                                  "Try using a larger noise or a smaller lengthscale.")      # :149
+        nat.check(rc)
+        if attempts.value > 1:                                                               # :144
+            warnings.warn(f"Noise got changed to {_r_num(noise_used.value)} to avoid errors in cholesky decomposition")
+        self._noise = noise_used.value
+        alpha = np.empty(n)
+        nat.check(nat.lib().gprc_gpr_get_alpha(self._model, alpha.ctypes.data))
+        lp = C.c_double()
+        nat.check(nat.lib().gprc_gpr_get_logp(self._model, C.byref(lp)))
+        self._alpha, self._logp = alpha, lp.value
+
+    @classmethod
+    def new(cls, *args, **kwargs):
+        """`GPR$new(...)` spelling of the constructor."""
+        return cls(*args, **kwargs)
+
+    def predict(self, X_star, pointwise_var=True):
+        """GPR$predict(X_star, pointwise_var = TRUE)  --  R/GPRclass.R:155-170.
+        pointwise: n* x 2 array cbind(mean, variance); otherwise [mean (n* x 1), covariance (n* x n*)]."""
+        d = self._X.shape[0]
+        Xs = np.asarray(X_star)
+        if Xs.dtype.kind not in "fiub" or Xs.size % d:
+            raise ValueError("is.numeric(X_star), length(X_star) %% nrow(self$X) == 0 are not all TRUE")  # :156
+        Xs = as_points(Xs, d=d, what="X_star") if Xs.ndim <= 1 else as_points(Xs, what="X_star")
+        if Xs.shape[0] != d:
+            raise ValueError("X_star must have nrow(X) rows")
+        ns = Xs.shape[1]
+        mean = np.empty(ns)
+        if pointwise_var:
+            var = np.empty(ns)
+            nat.check(nat.lib().gprc_gpr_predict(self._model, Xs.ctypes.data, ns, 1, mean.ctypes.data, var.ctypes.data))
+            return np.column_stack([mean, var])                                              # :165
+        cov = np.empty((ns, ns), order="F")
+        nat.check(nat.lib().gprc_gpr_predict(self._model, Xs.ctypes.data, ns, 0, mean.ctypes.data, cov.ctypes.data))
+        return [mean.reshape(-1, 1), cov]                                                    # :168
+
+    def _get_L(self):
+        if self._L is None:  # lazy: n x n doubles cross PCIe only when `$L` is read
+            n = self._X.shape[1]
+            L = np.empty((n, n), order="F")
+            nat.check(nat.lib().gprc_model_get_L(self._model, L.ctypes.data, n))
+            self._L = L
+        return self._L
+
+    X = _ReadOnly("X", lambda s: s._X)
+    k = _ReadOnly("k", lambda s: s._k)
+    y = _ReadOnly("y", lambda s: s._y)
+    noise = _ReadOnly("noise", lambda s: s._noise)
+    L = _ReadOnly("L", _get_L)
+    alpha = _ReadOnly("alpha", lambda s: s._alpha)
+    logp = _ReadOnly("logp", lambda s: s._logp)
+
+    def close(self):
+        if getattr(self, "_model", None):
+            nat.lib().gprc_model_free(self._model)
+            self._model = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _need(value, name, kernel):
+    if value is None:
+        raise NotImplementedError(f"GPR.{kernel}: `{name}` defaults to fit(X, y, noise, \"{kernel}\")$par in the reference; "
+                                  "fit() is not part of the MI355X hot path yet -- pass it explicitly")
+    return value
+
+
+def _len(x):
+    return np.size(x)
+
+
+class GPR_constant(GPR):
+    """GPR.constant$new(X, y, noise, c)  --  R/GPRclass.R:284-292."""
+
+    def __init__(self, X, y, noise, c=None, **kw):
+        c = _need(c, "c", "constant")
+        if not (np.isreal(c) and np.all(np.asarray(c) > 0)):
+            raise ValueError("is.numeric(c), c > 0 are not all TRUE")
+        super().__init__(X, y, noise, cov_func(constant, c=c), **kw)
+
+
+class GPR_linear(GPR):
+    """GPR.linear$new(X, y, noise, sigma)  --  R/GPRclass.R:295-303."""
+
+    def __init__(self, X, y, noise, sigma=None, **kw):
+        sigma = _need(sigma, "sigma", "linear")
+        if _len(sigma) != as_points(X).shape[0]:
+            raise ValueError("length(sigma) == nrow(X) is not TRUE")
+        super().__init__(X, y, noise, cov_func(linear, sigma=sigma), **kw)
+
+
+class GPR_polynomial(GPR):
+    """GPR.polynomial$new(X, y, noise, sigma, p)  --  R/GPRclass.R:306-315."""
+
+    def __init__(self, X, y, noise, sigma=None, p=None, **kw):
+        sigma, p = _need(sigma, "sigma", "polynomial"), _need(p, "p", "polynomial")
+        if _len(sigma) != 1 or _len(p) != 1:
+            raise ValueError("length(sigma) == 1, length(p) == 1 are not all TRUE")
+        super().__init__(X, y, noise, cov_func(polynomial, sigma=sigma, p=p), **kw)
+
+
+class GPR_sqrexp(GPR):
+    """GPR.sqrexp$new(X, y, noise, l)  --  R/GPRclass.R:318-327."""
+
+    def __init__(self, X, y, noise, l=None, **kw):
+        l = _need(l, "l", "sqrexp")
+        if _len(l) != 1:
+            raise ValueError("length(l) == 1 is not TRUE")
+        super().__init__(X, y, noise, cov_func(sqrexp, l=l), **kw)
+
+
+class GPR_gammaexp(GPR):
+    """GPR.gammaexp$new(X, y, noise, gamma, l)  --  R/GPRclass.R:330-339."""
+
+    def __init__(self, X, y, noise, gamma=None, l=None, **kw):
+        gamma, l = _need(gamma, "gamma", "gammaexp"), _need(l, "l", "gammaexp")
+        if _len(gamma) != 1 or _len(l) != 1:
+            raise ValueError("length(gamma) == 1, length(l) == 1 are not all TRUE")
+        super().__init__(X, y, noise, cov_func(gammaexp, l=l, gamma=gamma), **kw)
+
+
+class GPR_rationalquadratic(GPR):
+    """GPR.rationalquadratic$new(X, y, noise, alpha, l)  --  R/GPRclass.R:342-351."""
+
+    def __init__(self, X, y, noise, alpha=None, l=None, **kw):
+        alpha, l = _need(alpha, "alpha", "rationalquadratic"), _need(l, "l", "rationalquadratic")
+        if _len(alpha) != 1 or _len(l) != 1:
+            raise ValueError("length(alpha) == 1, length(l) == 1 are not all TRUE")
+        super().__init__(X, y, noise, cov_func(rationalquadratic, l=l, alpha=alpha), **kw)
+
+
+# `GPR.sqrexp$new(...)` reads `GPR.sqrexp.new(...)` here
+GPR.constant = GPR_constant
+GPR.linear = GPR_linear
+GPR.polynomial = GPR_polynomial
+GPR.sqrexp = GPR_sqrexp
+GPR.gammaexp = GPR_gammaexp
+GPR.rationalquadratic = GPR_rationalquadratic

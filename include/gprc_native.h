@@ -1,0 +1,170 @@
+/*
+ * gprc_native.h -- C ABI of the MI355X-native GP predict hot path (libgprc_native.so).
+ *
+ * Drop-in boundary for the R package `gprc` (MoHawastaken/Gaussian-Process-Regression).  The
+ * reference has NO FFI today (pure R closures / R6 methods); each entry point below names the
+ * reference interface (file:line under the reference root) whose arithmetic it replaces.  The `.Call`
+ * shim a maintainer adds on the R side is shown in INTEGRATION.md; the Python host mirror used by the
+ * tests binds the same symbols through ctypes.
+ *
+ * Conventions
+ *  - plain C, no R / torch / C++ types; sizes are int64_t; every matrix is column-major fp64;
+ *  - X is d x n with one observation per COLUMN (R/GPRclass.R:29,132,137): point i = X[i*d .. i*d+d);
+ *  - every data pointer may be HOST memory (the `.Call` case: REAL(x)) or DEVICE memory of the
+ *    context's GPU (the resident-data case: bench.py, the multi-GPU driver).  The library asks the HIP
+ *    runtime which it is; host data is staged through the context's stream, device data is used in
+ *    place.  Inputs are borrowed for the duration of the call only;
+ *  - return value: 0 = ok; > 0 = LAPACK-style info (order of the first leading minor that is not
+ *    positive definite -- what R's chol() reports, R/GPRclass.R:142); < 0 = gprc_status error, with
+ *    text in gprc_last_error().  The library never aborts, exits or throws across this boundary;
+ *  - a gprc_ctx is bound to one GPU and one HIP stream; calls on one context are serialised by the
+ *    caller (R's single thread).  Different contexts may be used from different threads/processes.
+ */
+#ifndef GPRC_NATIVE_H
+#define GPRC_NATIVE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPRC_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define GPRC_API __attribute__((visibility("default")))
+#else
+#define GPRC_API
+#endif
+
+/* Kernel ids and parameter vectors (the `...` of cov_func, R/GPRclass.R:424-427):
+ *   GPRC_CONSTANT     params = {c}               R/GPRclass.R:382
+ *   GPRC_LINEAR       params = {sigma} or sigma[d] R/GPRclass.R:386
+ *   GPRC_POLYNOMIAL   params = {sigma, p}        R/GPRclass.R:390
+ *   GPRC_SQREXP       params = {l}               R/GPRclass.R:394
+ *   GPRC_GAMMAEXP     params = {l, gamma}        R/GPRclass.R:398
+ *   GPRC_RATQUAD      params = {l, alpha}        R/GPRclass.R:402 */
+typedef enum {
+  GPRC_CONSTANT = 0,
+  GPRC_LINEAR = 1,
+  GPRC_POLYNOMIAL = 2,
+  GPRC_SQREXP = 3,
+  GPRC_GAMMAEXP = 4,
+  GPRC_RATQUAD = 5
+} gprc_kernel_id;
+
+typedef enum {
+  GPRC_OK = 0,
+  GPRC_ERR_ARG = -1,      /* bad argument (the reference's stopifnot() failures) */
+  GPRC_ERR_HIP = -2,      /* HIP runtime error */
+  GPRC_ERR_NOMEM = -3,    /* allocation failed */
+  GPRC_ERR_NOT_PD = -4,   /* all ten jitter attempts failed: "Inputs lead to non positive definite
+                             covariance matrix..." (R/GPRclass.R:149) */
+  GPRC_ERR_DIVERGED = -5, /* GPC: "Apparently does not converge." (R/GPCclass.R:90-91) */
+  GPRC_ERR_MAXITER = -6,  /* GPC: safety cap on IRLS iterations hit (the reference loops forever) */
+  GPRC_ERR_NO_DEVICE = -7 /* no usable gfx950 device */
+} gprc_status;
+
+typedef struct gprc_ctx gprc_ctx;     /* one GPU + one stream + scratch */
+typedef struct gprc_model gprc_model; /* fitted GPR or GPC: device-resident X, y, L, alpha / f_hat */
+
+/* ---- library / device --------------------------------------------------------------------- */
+GPRC_API int gprc_abi_version(void);
+/* text of the last error on the calling thread ("" if none); valid until the next failing call */
+GPRC_API const char* gprc_last_error(void);
+GPRC_API int gprc_device_count(int* count_out);
+/* stream: a hipStream_t owned by the caller (e.g. torch's current stream), or NULL to let the
+ * context create and own one. */
+GPRC_API int gprc_ctx_create(int device, void* stream, gprc_ctx** ctx_out);
+GPRC_API int gprc_ctx_destroy(gprc_ctx* ctx);
+GPRC_API int gprc_ctx_synchronize(gprc_ctx* ctx);
+
+/* ---- L1: covariance-function layer --------------------------------------------------------- */
+/* covariance_matrix(A, B, k) (R/GPRclass.R:355-357): out[i + j*ld_out] = k(A[,i], B[,j]),
+ * nA x nB.  ld_out >= nA. */
+GPRC_API int gprc_kernel_matrix(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* A, int64_t d,
+                       int64_t nA, const double* B, int64_t nB, double* out, int64_t ld_out);
+/* the closure contract itself (R/GPRclass.R:353-354, the .matrix methods :382-402): for two d x m
+ * matrices, out[c] = k(x[,c], y[,c]).  GPR$predict uses it for k(X*,X*) (R/GPRclass.R:164). */
+GPRC_API int gprc_kernel_colwise(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* x,
+                        const double* y, int64_t d, int64_t m, double* out);
+
+/* ---- L2: GPR ------------------------------------------------------------------------------ */
+/* One Cholesky attempt of GPR$initialize (R/GPRclass.R:138,142,152-153): K = k(X,X),
+ * L = chol(K + noise*I)^T, alpha = L^-T L^-1 y, logp.  Returns 0 and a model, or info > 0 (no model)
+ * when K + noise*I is not positive definite. */
+GPRC_API int gprc_gpr_fit(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d,
+                 int64_t n, const double* y, double noise, gprc_model** model_out);
+/* The whole of R/GPRclass.R:139-151: attempts noise, noise+0.01, ..., noise+0.09; *noise_used is
+ * the `$noise` the reference stores, *attempts > 1 means the reference would warn (:144).
+ * Returns GPRC_ERR_NOT_PD when all ten fail (:149). */
+GPRC_API int gprc_gpr_fit_retry(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d,
+                       int64_t n, const double* y, double noise, gprc_model** model_out, double* noise_used,
+                       int* attempts);
+/* GPR$predict (R/GPRclass.R:155-170).  X_star is d x n_star.
+ * pointwise != 0: mean_out[n_star], var_out[n_star] = k(x*,x*) - colSums(v*v)      (:164-165)
+ * pointwise == 0: mean_out[n_star], var_out = n_star x n_star K(X*,X*) - t(v) %*% v (:167-168) */
+GPRC_API int gprc_gpr_predict(gprc_model* model, const double* X_star, int64_t n_star, int pointwise, double* mean_out,
+                     double* var_out);
+/* active bindings (R/GPRclass.R:230-280).  get_L materialises the n x n lower factor (upper = 0,
+ * as t(chol(.)) has it) -- lazily, only when asked: it is 32 GiB at n = 65536. */
+GPRC_API int gprc_model_dims(const gprc_model* model, int64_t* n_out, int64_t* d_out);
+GPRC_API int gprc_model_get_L(gprc_model* model, double* L_out, int64_t ld_out);
+GPRC_API int gprc_gpr_get_alpha(gprc_model* model, double* alpha_out);
+GPRC_API int gprc_gpr_get_logp(gprc_model* model, double* logp_out);
+GPRC_API int gprc_gpr_get_noise(gprc_model* model, double* noise_out);
+GPRC_API int gprc_model_free(gprc_model* model);
+
+/* ---- L2: GPC ------------------------------------------------------------------------------ */
+/* GPC$initialize (R/GPCclass.R:66-107): Laplace mode by Newton/IRLS; y in {-1,+1}.
+ * max_iter <= 0 selects 1000.  *iters_out = the "Convergence after %s iterations" count (:98). */
+GPRC_API int gprc_gpc_fit(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d,
+                 int64_t n, const double* y, double epsilon, int max_iter, gprc_model** model_out, int* iters_out);
+/* the hot part of GPC$predict_class (R/GPCclass.R:109-115): fs_bar and Vfs for X_star. */
+GPRC_API int gprc_gpc_predict_latent(gprc_model* model, const double* X_star, int64_t n_star, double* fs_bar_out,
+                            double* Vfs_out);
+GPRC_API int gprc_gpc_get_f_hat(gprc_model* model, double* f_hat_out);
+GPRC_API int gprc_gpc_get_logq(gprc_model* model, double* logq_out);
+
+/* ---- device-level building blocks (multi-GPU driver, bench) ------------------------------- *
+ * All pointers below are DEVICE pointers on the context's GPU.  The factor lives in the packed
+ * block-column layout described in DESIGN.md: n_pad = gprc_pad(n); panel p holds rows
+ * [p*NB, n_pad) x columns [p*NB, (p+1)*NB), column-major with leading dimension n_pad - p*NB, at
+ * element offset gprc_panel_offset(n_pad, p); NB = gprc_panel_width().  Every panel is therefore one
+ * contiguous buffer: the unit RCCL broadcasts.  winv holds one 128 x 128 block per 128 columns
+ * (the inverse of the diagonal block of L), gprc_winv_size(n_pad) doubles. */
+GPRC_API int64_t gprc_panel_width(void);
+GPRC_API int64_t gprc_pad(int64_t n);
+GPRC_API int64_t gprc_panel_count(int64_t n_pad);
+GPRC_API int64_t gprc_panel_offset(int64_t n_pad, int64_t p);
+GPRC_API int64_t gprc_panel_elems(int64_t n_pad, int64_t p);
+GPRC_API int64_t gprc_packed_size(int64_t n_pad);
+GPRC_API int64_t gprc_winv_size(int64_t n_pad);
+/* fill panel p of K + noise*I (identity in the padding) */
+GPRC_API int gprc_dev_fill_panel(gprc_ctx* ctx, int kernel, const double* params_host, int n_params, const double* X,
+                        int64_t d, int64_t n, int64_t n_pad, double noise, double* packed, int64_t p);
+/* factor panel p in place (diagonal blocks in LDS, panel solves, in-panel updates); info_dev is a
+ * device int the first non-PD column (1-based) is written to (must be zeroed by the caller) */
+GPRC_API int gprc_dev_factor_panel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev);
+/* trailing update of panels q = q_begin, q_begin + q_stride, ... < q_end with factored panel p */
+GPRC_API int gprc_dev_update_trailing(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, int64_t q_begin,
+                             int64_t q_end, int64_t q_stride);
+/* b := L^-1 b (transpose == 0) or L^-T b (transpose != 0); work: gprc_trsv_work_size(n_pad) doubles */
+GPRC_API int64_t gprc_trsv_work_size(int64_t n_pad);
+GPRC_API int gprc_dev_trsv(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose,
+                  double* work);
+/* vt (m_pad x n_pad, ld = m_pad, m_pad % 128 == 0) = K(X_star, X), zero in the padding */
+GPRC_API int gprc_dev_fill_cross(gprc_ctx* ctx, int kernel, const double* params_host, int n_params, const double* X_star,
+                        int64_t d, int64_t m, int64_t m_pad, const double* X, int64_t n, int64_t n_pad, double* vt);
+/* out[i] = sum_j vt[i + j*ld] * w[j]  (w == NULL: sum_j vt[i,j]^2); work: rows * gprc_rowreduce_splits(cols) */
+GPRC_API int64_t gprc_rowreduce_splits(int64_t cols);
+GPRC_API int gprc_dev_row_reduce(gprc_ctx* ctx, const double* vt, int64_t ld, int64_t rows, int64_t cols, const double* w,
+                        double* out, double* work);
+/* vt := vt * L^-T  (row i becomes (L^-1 k_i)^T) */
+GPRC_API int gprc_dev_solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt,
+                        int64_t m_pad);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPRC_NATIVE_H */

@@ -1,0 +1,204 @@
+"""numpy front-end of the CPU oracle (oracle/gprc_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under gaussian-process-regression_amd/ may import this module.
+
+Conventions follow the reference: X is d x n (one observation per column); matrices are returned in
+the reference's orientation as numpy arrays (Fortran order where they are matrices).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+CONSTANT, LINEAR, POLYNOMIAL, SQREXP, GAMMAEXP, RATQUAD = range(6)
+KERNEL_IDS = {"constant": CONSTANT, "linear": LINEAR, "polynomial": POLYNOMIAL, "sqrexp": SQREXP,
+              "gammaexp": GAMMAEXP, "rationalquadratic": RATQUAD}
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+_i64 = C.c_int64
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with gcc (seconds)."""
+    src = os.path.join(_HERE, "gprc_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.oracle_threads.restype = C.c_int
+    return _lib
+
+
+def threads() -> int:
+    return lib().oracle_threads()
+
+
+def set_threads(t: int) -> None:
+    lib().oracle_set_threads(C.c_int(t))
+
+
+def _f(a):
+    return np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _par(params):
+    p = np.ascontiguousarray(np.asarray(params, dtype=np.float64).ravel())
+    return p, _p(p), C.c_int(p.size)
+
+
+def _as_points(X):
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim == 1:
+        X = X.reshape(1, -1)  # R/GPRclass.R:132: a vector becomes a 1 x n matrix
+    return np.asfortranarray(X)
+
+
+def kernel_colwise(kid, params, x, y):
+    x, y = _as_points(x), _as_points(y)
+    d, m = x.shape
+    out = np.empty(m)
+    p, pp, npar = _par(params)
+    rc = lib().oracle_kernel_colwise(C.c_int(kid), pp, npar, _p(x), _p(y), _i64(d), _i64(m), _p(out))
+    if rc:
+        raise ValueError("oracle_kernel_colwise: bad parameters")
+    return out
+
+
+def kernel_matrix(kid, params, A, B):
+    A, B = _as_points(A), _as_points(B)
+    d, nA = A.shape
+    nB = B.shape[1]
+    out = np.empty((nA, nB), order="F")
+    p, pp, npar = _par(params)
+    rc = lib().oracle_kernel_matrix(C.c_int(kid), pp, npar, _p(A), _i64(d), _i64(nA), _p(B), _i64(nB), _p(out))
+    if rc:
+        raise ValueError("oracle_kernel_matrix: bad parameters")
+    return out
+
+
+def potrf_lower(A, blocked=False):
+    """Returns (L, info); L has the upper triangle zeroed when info == 0."""
+    A = np.array(A, dtype=np.float64, order="F", copy=True)
+    n = A.shape[0]
+    fn = lib().oracle_potrf_lower_blocked if blocked else lib().oracle_potrf_lower
+    fn.restype = C.c_int
+    info = fn(_p(A), _i64(n), _i64(n))
+    return (np.tril(A) if info == 0 else A), info
+
+
+def gpr_fit(kid, params, X, y, noise):
+    """GPR$initialize: dict(L, alpha, logp, noise, attempts, info_first); raises ArithmeticError if all 10 fail."""
+    X = _as_points(X)
+    d, n = X.shape
+    y = np.ascontiguousarray(np.asarray(y, dtype=np.float64))
+    L = np.empty((n, n), order="F")
+    alpha = np.empty(n)
+    logp = C.c_double()
+    nz = C.c_double()
+    att = C.c_int()
+    info1 = C.c_int()
+    p, pp, npar = _par(params)
+    rc = lib().oracle_gpr_fit(C.c_int(kid), pp, npar, _p(X), _i64(d), _i64(n), _p(y), C.c_double(noise), _p(L), _p(alpha),
+                              C.byref(logp), C.byref(nz), C.byref(att), C.byref(info1))
+    if rc == 1:
+        raise ArithmeticError("Inputs lead to non positive definite covariance matrix.")
+    if rc:
+        raise ValueError(f"oracle_gpr_fit rc={rc}")
+    return dict(L=L, alpha=alpha, logp=logp.value, noise=nz.value, attempts=att.value, info_first=info1.value)
+
+
+def gpr_predict(kid, params, X, L, alpha, Xs, pointwise=True):
+    X, Xs = _as_points(X), None if Xs is None else np.asarray(Xs, dtype=np.float64)
+    d, n = X.shape
+    if Xs.ndim == 1:
+        Xs = Xs.reshape(d, -1, order="F")  # R/GPRclass.R:157-159
+    Xs = np.asfortranarray(Xs)
+    ns = Xs.shape[1]
+    L = _f(L)
+    alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+    mean = np.empty(ns)
+    var = np.empty(ns) if pointwise else np.empty((ns, ns), order="F")
+    p, pp, npar = _par(params)
+    rc = lib().oracle_gpr_predict(C.c_int(kid), pp, npar, _p(X), _i64(d), _i64(n), _p(L), _p(alpha), _p(Xs), _i64(ns),
+                                  C.c_int(1 if pointwise else 0), _p(mean), _p(var))
+    if rc:
+        raise ValueError(f"oracle_gpr_predict rc={rc}")
+    return mean, var
+
+
+def gpc_fit(kid, params, X, y, epsilon=1e-5, max_iter=1000):
+    X = _as_points(X)
+    d, n = X.shape
+    y = np.ascontiguousarray(np.asarray(y, dtype=np.float64))
+    L = np.empty((n, n), order="F")
+    f_hat = np.empty(n)
+    logq = C.c_double()
+    iters = C.c_int()
+    p, pp, npar = _par(params)
+    rc = lib().oracle_gpc_fit(C.c_int(kid), pp, npar, _p(X), _i64(d), _i64(n), _p(y), C.c_double(epsilon), C.c_int(max_iter),
+                              _p(f_hat), _p(L), C.byref(logq), C.byref(iters))
+    if rc == 2:
+        raise ArithmeticError("Apparently does not converge.")
+    if rc:
+        raise ValueError(f"oracle_gpc_fit rc={rc}")
+    return dict(f_hat=f_hat, L=L, logq=logq.value, iters=iters.value)
+
+
+def gpc_predict_latent(kid, params, X, y, f_hat, L, Xs):
+    X = _as_points(X)
+    d, n = X.shape
+    Xs = np.asarray(Xs, dtype=np.float64)
+    if Xs.ndim == 1:
+        Xs = Xs.reshape(1, -1)  # R/GPCclass.R:109
+    Xs = np.asfortranarray(Xs)
+    ns = Xs.shape[1]
+    y = np.ascontiguousarray(np.asarray(y, dtype=np.float64))
+    f_hat = np.ascontiguousarray(f_hat, dtype=np.float64)
+    L = _f(L)
+    fs = np.empty(ns)
+    vf = np.empty(ns)
+    p, pp, npar = _par(params)
+    rc = lib().oracle_gpc_predict_latent(C.c_int(kid), pp, npar, _p(X), _i64(d), _i64(n), _p(y), _p(f_hat), _p(L), _p(Xs),
+                                         _i64(ns), _p(fs), _p(vf))
+    if rc:
+        raise ValueError(f"oracle_gpc_predict_latent rc={rc}")
+    return fs, vf
+
+
+def gpr_fit_predict_blocked(kid, params, X, y, noise, Xs):
+    """The timed CPU baseline shape: one blocked fit + pointwise predict.  Returns dict."""
+    X, Xs = _as_points(X), _as_points(Xs)
+    d, n = X.shape
+    ns = Xs.shape[1]
+    y = np.ascontiguousarray(np.asarray(y, dtype=np.float64))
+    L = np.empty((n, n), order="F")
+    work = np.empty((ns, n), order="F")
+    alpha = np.empty(n)
+    mean = np.empty(ns)
+    var = np.empty(ns)
+    logp = C.c_double()
+    p, pp, npar = _par(params)
+    fn = lib().oracle_gpr_fit_predict_blocked
+    fn.restype = C.c_int
+    info = fn(C.c_int(kid), pp, npar, _p(X), _i64(d), _i64(n), _p(y), C.c_double(noise), _p(Xs), _i64(ns), _p(L), _p(work),
+              _p(alpha), C.byref(logp), _p(mean), _p(var))
+    return dict(info=info, L=np.tril(L), alpha=alpha, logp=logp.value, mean=mean, var=var)
