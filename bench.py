@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- the GP predict step (fit + predict) on N MI355X GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic problem: kernel fill of K + noise*I, blocked
+fp64 Cholesky, alpha and logp (the reference's GPR$new, R/GPRclass.R:127-154) followed by the pointwise
+GPR$predict (R/GPRclass.R:155-165) on the reference's own test grid (R/simulation.R:101-102).  Inputs are
+resident in HBM when the timed region starts.  Default workload: BASELINE.json configs[3] (C4), n = 65536,
+d = 8, sqexp, n* = 4^8 = 65536 -- the configuration the metric's target is quoted on; it fits one GPU and
+is the same at every N (strong scaling).  `--workload c2|c3` select the other single-GPU configs.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant kernel, HIP
+events recorded inside the native library on the launching stream) and, at N = 1, `cpu_baseline` (the
+oracle's blocked OpenMP port on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X spec, fp64 matrix (dense); measured 77.5 by tools/microbench/mfma_f64.hip
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+WORKLOADS = {
+    # name: (n, d, kernel name, params, n_star or None -> reference grid rule)
+    "c1": (256, 1, "sqrexp", [1.0], None),
+    "c2": (8192, 8, "sqrexp", [1.0], None),
+    "c3": (32768, 8, "rationalquadratic", [1.0, 1.5], None),
+    "c4": (65536, 8, "sqrexp", [1.0], None),
+}
+KERNEL_IDS = {"constant": 0, "linear": 1, "polynomial": 2, "sqrexp": 3, "gammaexp": 4, "rationalquadratic": 5}
+SEED = 20261004
+
+
+def synth(n, d, n_star):
+    """BASELINE.md inputs: X ~ U[-1,1]^(d x n), y = 0.1*sum(x^3) + N(0, 0.1^2); test grid = combine_all of
+    ceil(10000^(1/d)) equispaced points per axis (R/simulation.R:101-102, 338-349), first axis slowest."""
+    rng = np.random.Generator(np.random.Philox(SEED))
+    X = rng.uniform(-1.0, 1.0, size=(n, d))                      # row i = point i  (== d x n column-major)
+    y = 0.1 * (X ** 3).sum(1) + rng.normal(0.0, 0.1, size=n)
+    if n_star is None:
+        per = math.ceil(10000 ** (1.0 / d) - 1e-9)
+        axes = [np.linspace(-1.0, 1.0, per)] * d
+        Xs = np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(-1, d)
+    else:
+        Xs = rng.uniform(-1.0, 1.0, size=(n_star, d))
+    return np.ascontiguousarray(X), y, np.ascontiguousarray(Xs)
+
+
+def step_flops(n, ns):
+    """end-to-end algorithmic flops of one predict step."""
+    return n ** 3 / 3.0 + float(n) * n * ns + 2.0 * n * n + 4.0 * n * ns
+
+
+def cpu_baseline(kname, params, d, budget_s=15.0):
+    """Oracle (blocked OpenMP port of the same algorithm) on a bounded sample of the workload."""
+    from oracle import oracle as orc
+    cores = min(16, os.cpu_count() or 1)
+    orc.set_threads(cores)
+    kid = KERNEL_IDS[kname]
+
+    def run(n, ns):
+        X, y, Xs = synth(n, d, ns)
+        t0 = time.perf_counter()
+        r = orc.gpr_fit_predict_blocked(kid, params, X.T, y, 0.1, Xs.T)
+        dt = time.perf_counter() - t0
+        assert r["info"] == 0
+        return dt
+
+    t_cal = run(1024, 1024)
+    rate = step_flops(1024, 1024) / t_cal
+    n = 1024
+    while n < 8192 and step_flops(2 * n, 2 * n) / rate < budget_s:
+        n *= 2
+    dt = run(n, n) if n > 1024 else t_cal
+    return {"value": round(step_flops(n, n) / dt * 1e-12, 5), "unit": "TFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"oracle_gpr_fit_predict_blocked (OpenMP, {cores} threads) on n={n}, n*={n}, d={d}, {kname}: {dt:.2f} s"}
+
+
+def parity_gate(eng_factory, comm, dev_ops_cls):
+    """Small fit+predict through the same engine against the oracle (normwise 1e-10) before timing."""
+    from oracle import oracle as orc
+    n, d, ns = 1536, 8, 512
+    X, y, Xs = synth(n, d, ns)
+    eng, ops, bufs = eng_factory(n, d, "sqrexp", [1.0], X, y, Xs)
+    info = eng.fit(bufs["X"], bufs["y"])
+    assert info == 0
+    lo, hi = eng.slice_bounds(ns, comm.world)[comm.rank]
+    eng.predict_local(bufs["X"], bufs["y"], bufs["Xs_local"], hi - lo, bufs["mean"], bufs["var"])
+    mean = ops.to_host(bufs["mean"])[: hi - lo]
+    var = ops.to_host(bufs["var"])[: hi - lo]
+    ref = orc.gpr_fit(orc.SQREXP, [1.0], X.T, y, 0.1)
+    mr, vr = orc.gpr_predict(orc.SQREXP, [1.0], X.T, ref["L"], ref["alpha"], Xs.T)
+    e1 = np.abs(mean - mr[lo:hi]).max() / np.abs(mr).max() if hi > lo else 0.0
+    e2 = np.abs(var - vr[lo:hi]).max() / np.abs(vr).max() if hi > lo else 0.0
+    ops.close()
+    assert e1 <= 1e-10 and e2 <= 1e-10, (e1, e2)
+    return max(e1, e2)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--n", type=int, default=0, help="override n")
+    ap.add_argument("--nstar", type=int, default=0, help="override n* (random test points instead of the grid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import gprc_amd
+    from gprc_amd import _native as nat
+    from gprc_amd.distributed import DistributedGPR, HipOps, SingleComm, TorchComm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the gprc native path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        comm = TorchComm()
+    else:
+        comm = SingleComm()
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
+
+    n, d, kname, params, n_star = WORKLOADS[args.workload]
+    if args.n:
+        n = args.n
+    if args.nstar:
+        n_star = args.nstar
+
+    def make_engine(n_, d_, kname_, params_, X, y, Xs):
+        ops = HipOps(local_rank, KERNEL_IDS[kname_], params_, d_, n_, 0.1)
+        eng = DistributedGPR(ops, comm)
+        g = ops.geom
+        ypad = np.zeros(g.n_pad)
+        ypad[:n_] = y
+        ns_ = Xs.shape[0]
+        lo, hi = eng.slice_bounds(ns_, comm.world)[comm.rank]
+        width = max(hi - lo, 1)
+        bufs = {"X": ops.from_host(X), "y": ops.from_host(ypad),
+                "Xs_local": ops.from_host(Xs[lo:hi] if hi > lo else np.zeros((1, d_))),
+                "mean": ops.zeros(width), "var": ops.zeros(width)}
+        ops.synchronize()
+        return eng, ops, bufs
+
+    gate_err = None
+    if not args.no_parity_gate:
+        gate_err = parity_gate(make_engine, comm, HipOps)
+
+    X, y, Xs = synth(n, d, n_star)
+    ns = Xs.shape[0]
+    eng, ops, bufs = make_engine(n, d, kname, params, X, y, Xs)
+    lo, hi = eng.slice_bounds(ns, world)[rank]
+
+    def step():
+        info = eng.fit(bufs["X"], bufs["y"])
+        if info != 0:
+            raise RuntimeError(f"K + noise*I not positive definite (info={info})")
+        eng.predict_local(bufs["X"], bufs["y"], bufs["Xs_local"], hi - lo, bufs["mean"], bufs["var"])
+
+    def fence():
+        ops.synchronize()
+        comm.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    nat.lib().gprc_prof_reset()
+    nat.lib().gprc_prof_enable(1 if rank == 0 else 0)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    nat.lib().gprc_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    mean = ops.to_host(bufs["mean"])[: hi - lo]
+    var = ops.to_host(bufs["var"])[: hi - lo]
+    sane = bool(np.isfinite(mean).all() and np.isfinite(var).all() and (var > -1e-8).all())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        flops = step_flops(n, ns)
+        prof = nat.prof_summary()
+        kernels = {}
+        for name, r in prof.items():
+            if r["count"] == 0:
+                continue
+            kernels[name] = {"launches": r["count"], "ms_total": round(r["ms"], 3), "avg_ms": round(r["ms"] / r["count"], 4),
+                             "tflops": round(r["flops"] / r["ms"] * 1e-9, 3) if r["ms"] > 0 else None,
+                             "gbs": round(r["bytes"] / r["ms"] * 1e-6, 1) if r["ms"] > 0 else None}
+        dom_name = max(("solve_update_k512", "trailing_update"), key=lambda k: prof[k]["ms"])
+        dom = prof[dom_name]
+        achieved = dom["flops"] / dom["ms"] * 1e-9 if dom["ms"] > 0 else 0.0
+        symbol = {"solve_update_k512": "gemm_nt_kernel<5>", "trailing_update": "trailing_kernel"}[dom_name]
+        out = {
+            "metric": "GPR predict-step achieved fp64 TFLOP/s (kernel fill + Cholesky + solves + mean/variance), n x n sqexp",
+            "value": round(flops / (elapsed / args.steps) * 1e-12, 4),
+            "unit": "TFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: n={n} d={d} {kname} GPR fit+predict, n*={ns} (reference test-grid rule), noise=0.1",
+                       "n": n, "d": d, "n_star": ns, "kernel": kname, "kernel_params": params,
+                       "parallelism": f"1-D block-cyclic 512-column panels over {world} GPU(s), test points sliced"},
+            "roofline": {"bound": "mfma", "kernel": symbol, "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches": dom["count"], "avg_launch_ms": round(dom["ms"] / max(dom["count"], 1), 4)},
+            "kernels": kernels,
+            "frac_of_fp64_peak_end_to_end": round(flops / (elapsed / args.steps) * 1e-12 / (FP64_MFMA_PEAK_TFLOPS * world), 4),
+            "parity_gate_normwise_err": gate_err,
+            "outputs_sane": sane,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kname, params, d)
+        print(json.dumps(out), flush=True)
+    ops.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,12 +13,13 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgprc_native.so")
+LIB_PATH = os.path.join(_HERE, "lib", "libgprc_native" + os.environ.get("GPRC_LIB_SUFFIX", "") + ".so")
 
 # kernel ids (include/gprc_native.h gprc_kernel_id)
 CONSTANT, LINEAR, POLYNOMIAL, SQREXP, GAMMAEXP, RATQUAD = range(6)
 
 OK = 0
+GPC_REFERENCE_STOP = 1
 ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_NOT_PD, ERR_DIVERGED, ERR_MAXITER, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
 
 
@@ -63,7 +64,7 @@ PROTOTYPES = {
     "gprc_gpr_get_logp": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "gprc_gpr_get_noise": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "gprc_model_free": (C.c_int, [_vp]),
-    "gprc_gpc_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, C.c_double, C.c_int, C.POINTER(_vp),
+    "gprc_gpc_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, C.c_double, C.c_int, C.c_int, C.POINTER(_vp),
                                C.POINTER(C.c_int)]),
     "gprc_gpc_predict_latent": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "gprc_gpc_get_f_hat": (C.c_int, [_vp, _vp]),
@@ -80,10 +81,17 @@ PROTOTYPES = {
     "gprc_dev_update_trailing": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64]),
     "gprc_trsv_work_size": (_i64, [_i64]),
     "gprc_dev_trsv": (C.c_int, [_vp, _vp, _vp, _i64, _vp, C.c_int, _vp]),
-    "gprc_dev_fill_cross": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp]),
+    "gprc_dev_fill_cross": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64]),
     "gprc_rowreduce_splits": (_i64, [_i64]),
     "gprc_dev_row_reduce": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
-    "gprc_dev_solve_rows": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64]),
+    "gprc_dev_logp": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "gprc_gpr_model_from_device": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, _vp, _vp, _vp, C.c_double,
+                                             C.c_double, C.POINTER(_vp)]),
+    "gprc_prof_enable": (C.c_int, [C.c_int]),
+    "gprc_prof_reset": (C.c_int, []),
+    "gprc_prof_kinds": (C.c_int, []),
+    "gprc_prof_summary": (C.c_int, [C.c_int, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "gprc_dev_solve_rows": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i64]),
 }
 
 _lib = None
@@ -127,6 +135,20 @@ def device_count() -> int:
     c = C.c_int(0)
     check(lib().gprc_device_count(C.byref(c)))
     return c.value
+
+
+PROF_KINDS = ["fill", "potf2_inv", "trsm_panel", "gemm_inner_k128", "trailing_update", "solve_update_k512", "trsv",
+              "row_reduce", "cov_syrk"]
+
+
+def prof_summary():
+    """{kind: dict(count, ms, flops, bytes)} of the launches seen since gprc_prof_reset()."""
+    out = {}
+    for kind, name in enumerate(PROF_KINDS):
+        cnt, ms, fl, by = _i64(), C.c_double(), C.c_double(), C.c_double()
+        check(lib().gprc_prof_summary(kind, C.byref(cnt), C.byref(ms), C.byref(fl), C.byref(by)))
+        out[name] = dict(count=cnt.value, ms=ms.value, flops=fl.value, bytes=by.value)
+    return out
 
 
 def params_array(params):

@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# Builds libgprc_native.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+# Builds libgprc_native$SUFFIX.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
 # -amdgpu-mfma-vgpr-form keeps MFMA accumulators in VGPRs: without it hipcc bounces the 128
 # accumulator registers through AGPRs around every loop iteration (measured 36 vs 77 TFLOP/s).
 set -euo pipefail
@@ -7,12 +7,14 @@ here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../lib"
 mkdir -p "$out"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 -Wall -Wno-unused-function)
+NBW="${GPRC_NB:-512}"
+SUFFIX="${GPRC_LIB_SUFFIX:-}"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 -Wall -Wno-unused-function -DGPRC_NB="$NBW")
 objs=()
 for src in gprc_api kernels_fill kernels_chol kernels_vec; do
-  "$HIPCC" "${FLAGS[@]}" -c "$here/$src.hip" -o "$out/$src.o" &
-  objs+=("$out/$src.o")
+  "$HIPCC" "${FLAGS[@]}" -c "$here/$src.hip" -o "$out/$src$SUFFIX.o" &
+  objs+=("$out/$src$SUFFIX.o")
 done
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libgprc_native.so" "${objs[@]}"
-echo "built $out/libgprc_native.so"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libgprc_native$SUFFIX.so" "${objs[@]}"
+echo "built $out/libgprc_native$SUFFIX.so"

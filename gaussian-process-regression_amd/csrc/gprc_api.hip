@@ -25,6 +25,38 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   return e == hipErrorOutOfMemory ? GPRC_ERR_NOMEM : GPRC_ERR_HIP;
 }
 
+// ---- event profiler ------------------------------------------------------------------------------
+namespace {
+struct ProfRec { int kind; double flops, bytes; hipEvent_t e0, e1; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+std::vector<ProfRec> g_prof_open;  // begun, not ended (per kind nesting is not used)
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+bool prof_enabled() { return g_prof_on; }
+void prof_begin(hipStream_t s, int kind) {
+  ProfRec r{kind, 0.0, 0.0, prof_event(), nullptr};
+  (void)hipEventRecord(r.e0, s);
+  g_prof_open.push_back(r);
+}
+void prof_end(hipStream_t s, int kind, double flops, double bytes) {
+  for (size_t i = g_prof_open.size(); i-- > 0;) {
+    if (g_prof_open[i].kind != kind) continue;
+    ProfRec r = g_prof_open[i];
+    g_prof_open.erase(g_prof_open.begin() + (long)i);
+    r.flops = flops; r.bytes = bytes; r.e1 = prof_event();
+    (void)hipEventRecord(r.e1, s);
+    g_prof_recs.push_back(r);
+    return;
+  }
+}
+
 }  // namespace gprc
 
 using namespace gprc;
@@ -36,6 +68,7 @@ struct gprc_ctx {
   int* info_dev = nullptr;     // LAPACK info written by the diagonal-block kernel
   double* scal_dev = nullptr;  // 8 doubles of scalar results
   size_t chunk_bytes = (size_t)16 << 30;  // budget for one K_star^T chunk
+  int64_t vt_pad = 0;                     // extra doubles in the chunk's leading dimension (keeps it off powers of two)
 };
 
 enum ModelType { MODEL_GPR = 1, MODEL_GPC = 2 };
@@ -54,6 +87,7 @@ struct gprc_model {
   double* sw = nullptr;      // GPC sqrt(W)
   double* work = nullptr;    // trsv partials
   double logp = 0.0, noise = 0.0, logq = 0.0;
+  bool borrowed = false;     // X, y, packed, winv, alpha belong to the caller
 };
 
 namespace {
@@ -151,7 +185,7 @@ int factor_panel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, double
     double* Lcol = pan + (cj + NBI) + cj * ld;
     GPRC_TRY(launch_trsm_panel(s, Lcol, ld, below, wblk));
     const int64_t rest = NB - cj - NBI;  // remaining columns of this panel
-    if (rest > 0) GPRC_TRY(launch_gemm_nt(s, pan + (cj + NBI) + (cj + NBI) * ld, ld, Lcol, ld, Lcol, ld, below, rest, NBI, 1));
+    if (rest > 0) GPRC_TRY(launch_gemm_nt(s, pan + (cj + NBI) + (cj + NBI) * ld, ld, Lcol, ld, Lcol, ld, below, rest, NBI, 1, PK_GEMM_INNER));
   }
   return 0;
 }
@@ -170,7 +204,7 @@ int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* 
 }
 
 // vt (m_pad x n_pad) := vt * L^-T
-int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt, int64_t m_pad) {
+int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt, int64_t ldv, int64_t m_pad) {
   hipStream_t s = ctx->stream;
   const int64_t P = n_pad / NB;
   for (int64_t p = 0; p < P; ++p) {
@@ -179,15 +213,15 @@ int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t 
     for (int j = 0; j < NB / NBI; ++j) {
       const int64_t cj = p * NB + (int64_t)j * NBI;  // global column
       const double* wblk = winv + (p * (NB / NBI) + j) * NBI * NBI;
-      GPRC_TRY(launch_trsm_panel(s, vt + cj * m_pad, m_pad, m_pad, wblk));
+      GPRC_TRY(launch_trsm_panel(s, vt + cj * ldv, ldv, m_pad, wblk));
       const int64_t rest = NB - (j + 1) * NBI;
       if (rest > 0)
-        GPRC_TRY(launch_gemm_nt(s, vt + (cj + NBI) * m_pad, m_pad, vt + cj * m_pad, m_pad, pan + (j + 1) * NBI + (int64_t)j * NBI * ld, ld,
-                                m_pad, rest, NBI, 0));
+        GPRC_TRY(launch_gemm_nt(s, vt + (cj + NBI) * ldv, ldv, vt + cj * ldv, ldv, pan + (j + 1) * NBI + (int64_t)j * NBI * ld, ld,
+                                m_pad, rest, NBI, 0, PK_GEMM_INNER));
     }
     const int64_t right = n_pad - (p + 1) * NB;
     if (right > 0)
-      GPRC_TRY(launch_gemm_nt(s, vt + (p + 1) * NB * m_pad, m_pad, vt + p * NB * m_pad, m_pad, pan + NB, ld, m_pad, right, NB, 0));
+      GPRC_TRY(launch_gemm_nt(s, vt + (p + 1) * NB * ldv, ldv, vt + p * NB * ldv, ldv, pan + NB, ld, m_pad, right, NB, 0, PK_SOLVE_UPDATE));
   }
   return 0;
 }
@@ -195,6 +229,7 @@ int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t 
 void free_model(gprc_model* m) {
   if (!m) return;
   if (m->ctx) (void)hipSetDevice(m->ctx->device);
+  if (m->borrowed) m->X = m->y = m->packed = m->winv = m->alpha = nullptr;
   for (double* p : {m->X, m->y, m->packed, m->winv, m->alpha, m->f_hat, m->sw, m->work})
     if (p) (void)hipFree(p);
   delete m;
@@ -267,7 +302,7 @@ int gpr_prepare(gprc_ctx* ctx, int kernel, const double* params, int n_params, c
 }
 
 int chunk_rows(const gprc_ctx* ctx, int64_t n_pad, int64_t ns) {
-  int64_t rows = (int64_t)(ctx->chunk_bytes / (sizeof(double) * (size_t)n_pad)) / 128 * 128;
+  int64_t rows = ((int64_t)(ctx->chunk_bytes / (sizeof(double) * (size_t)n_pad)) - ctx->vt_pad) / 128 * 128;
   if (rows < 128) rows = 128;
   const int64_t need = pad_up(ns, 128);
   return (int)(rows < need ? rows : need);
@@ -312,6 +347,10 @@ int gprc_ctx_create(int device, void* stream, gprc_ctx** ctx_out) {
   hipError_t e = hipMalloc(&ctx->info_dev, 64);
   if (e == hipSuccess) e = hipMalloc(&ctx->scal_dev, 64);
   if (e != hipSuccess) { gprc_ctx_destroy(ctx); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
+  if (const char* vp = std::getenv("GPRC_VT_PAD")) {
+    const long long v = std::atoll(vp);
+    if (v >= 0 && v % 2 == 0) ctx->vt_pad = v;
+  }
   if (const char* cb = std::getenv("GPRC_CHUNK_BYTES")) {
     const long long v = std::atoll(cb);
     if (v > 0) ctx->chunk_bytes = (size_t)v;
@@ -434,8 +473,9 @@ int gprc_gpr_predict(gprc_model* m, const double* X_star, int64_t ns, int pointw
   GPRC_TRY(var.set(var_out, pointwise ? ns : ns * ns));
 
   const int64_t rows = pointwise ? chunk_rows(ctx, n_pad, ns) : pad_up(ns, 128);
+  const int64_t ldv = rows + ctx->vt_pad;  // one leading dimension for every chunk
   DevMem vt, red, tmp;
-  GPRC_TRY(vt.alloc(rows * n_pad));
+  GPRC_TRY(vt.alloc(ldv * n_pad));
   GPRC_TRY(red.alloc(rows * rowreduce_splits(n_pad)));
   GPRC_TRY(tmp.alloc(3 * rows));
   double* mean_c = tmp.p;
@@ -447,10 +487,10 @@ int gprc_gpr_predict(gprc_model* m, const double* X_star, int64_t ns, int pointw
       const int64_t mcur = (ns - s0 < rows) ? ns - s0 : rows;
       const int64_t m_pad = pad_up(mcur, 128);
       const double* xc = xs.dev + s0 * d;
-      GPRC_TRY(launch_fill(s, m->ks, xc, mcur, m->X, n, d, vt.p, m_pad, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0));  // K_star^T  :160
-      GPRC_TRY(launch_row_reduce(s, vt.p, m_pad, m_pad, n_pad, m->alpha, mean_c, red.p));                      // :161
-      GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt.p, m_pad));                                        // :162
-      GPRC_TRY(launch_row_reduce(s, vt.p, m_pad, m_pad, n_pad, nullptr, ss_c, red.p));                          // colSums(v*v)
+      GPRC_TRY(launch_fill(s, m->ks, xc, mcur, m->X, n, d, vt.p, ldv, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0));  // K_star^T  :160
+      GPRC_TRY(launch_row_reduce(s, vt.p, ldv, m_pad, n_pad, m->alpha, mean_c, red.p));                      // :161
+      GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt.p, ldv, m_pad));                                 // :162
+      GPRC_TRY(launch_row_reduce(s, vt.p, ldv, m_pad, n_pad, nullptr, ss_c, red.p));                          // colSums(v*v)
       GPRC_TRY(launch_colwise(s, m->ks, xc, xc, d, mcur, kss_c));                                               // k(X*,X*)  :164
       GPRC_TRY(launch_sub(s, kss_c, ss_c, var.dev + s0, mcur));
       GPRC_HIP(hipMemcpyAsync(mean.dev + s0, mean_c, sizeof(double) * mcur, hipMemcpyDeviceToDevice, s));
@@ -459,11 +499,11 @@ int gprc_gpr_predict(gprc_model* m, const double* X_star, int64_t ns, int pointw
     const int64_t m_pad = rows;
     DevMem cov;
     GPRC_TRY(cov.alloc(m_pad * m_pad));
-    GPRC_TRY(launch_fill(s, m->ks, xs.dev, ns, m->X, n, d, vt.p, m_pad, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0));
-    GPRC_TRY(launch_row_reduce(s, vt.p, m_pad, m_pad, n_pad, m->alpha, mean_c, red.p));
-    GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt.p, m_pad));
+    GPRC_TRY(launch_fill(s, m->ks, xs.dev, ns, m->X, n, d, vt.p, ldv, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0));
+    GPRC_TRY(launch_row_reduce(s, vt.p, ldv, m_pad, n_pad, m->alpha, mean_c, red.p));
+    GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt.p, ldv, m_pad));
     GPRC_TRY(launch_fill(s, m->ks, xs.dev, ns, xs.dev, ns, d, cov.p, m_pad, 0, m_pad, 0, m_pad, PAD_ZERO, 0.0));  // :167
-    GPRC_TRY(launch_gemm_nt(s, cov.p, m_pad, vt.p, m_pad, vt.p, m_pad, m_pad, m_pad, n_pad, 0));                  // - t(v) %*% v
+    GPRC_TRY(launch_gemm_nt(s, cov.p, m_pad, vt.p, ldv, vt.p, ldv, m_pad, m_pad, n_pad, 0, PK_COV_SYRK));                  // - t(v) %*% v
     GPRC_HIP(hipMemcpy2DAsync(var.dev, sizeof(double) * ns, cov.p, sizeof(double) * m_pad, sizeof(double) * ns, ns,
                               hipMemcpyDeviceToDevice, s));
     GPRC_HIP(hipMemcpyAsync(mean.dev, mean_c, sizeof(double) * ns, hipMemcpyDeviceToDevice, s));
@@ -525,7 +565,8 @@ int gprc_model_free(gprc_model* m) {
 
 // ---- GPC ----------------------------------------------------------------------------------------
 int gprc_gpc_fit(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d,
-                 int64_t n, const double* y, double epsilon, int max_iter, gprc_model** model_out, int* iters_out) {
+                 int64_t n, const double* y, double epsilon, int max_iter, int flags, gprc_model** model_out,
+                 int* iters_out) {
   GPRC_TRY(check_fit_args(ctx, X, d, n, y, model_out));
   if (!(epsilon > 0.0)) { set_error("epsilon must be > 0"); return GPRC_ERR_ARG; }  // R/GPCclass.R:68
   if (max_iter <= 0) max_iter = 1000;
@@ -574,7 +615,7 @@ int gprc_gpc_fit(gprc_ctx* ctx, int kernel, const double* params, int n_params, 
     GPC_HIP(hipStreamSynchronize(s));
     if (it > 1) {
       if (std::fabs(objective - last_objective) < epsilon) break;                          // :88
-      else if (least_objective + 10.0 < objective) { status = GPRC_ERR_DIVERGED; break; }  // :90
+      else if ((flags & GPRC_GPC_REFERENCE_STOP) && least_objective + 10.0 < objective) { status = GPRC_ERR_DIVERGED; break; }  // :90
     } else {
       least_objective = objective;
     }
@@ -619,8 +660,9 @@ int gprc_gpc_predict_latent(gprc_model* m, const double* X_star, int64_t ns, dou
   GPRC_TRY(fs.set(fs_bar_out, ns));
   GPRC_TRY(vf.set(Vfs_out, ns));
   const int64_t rows = chunk_rows(ctx, n_pad, ns);
+  const int64_t ldv = rows + ctx->vt_pad;
   DevMem vt, red, tmp;
-  GPRC_TRY(vt.alloc(rows * n_pad));
+  GPRC_TRY(vt.alloc(ldv * n_pad));
   GPRC_TRY(red.alloc(rows * rowreduce_splits(n_pad)));
   GPRC_TRY(tmp.alloc(3 * rows));
   double *mean_c = tmp.p, *ss_c = tmp.p + rows, *kss_c = tmp.p + 2 * rows;
@@ -628,11 +670,11 @@ int gprc_gpc_predict_latent(gprc_model* m, const double* X_star, int64_t ns, dou
     const int64_t mcur = (ns - s0 < rows) ? ns - s0 : rows;
     const int64_t m_pad = pad_up(mcur, 128);
     const double* xc = xs.dev + s0 * d;
-    GPRC_TRY(launch_fill(s, m->ks, xc, mcur, m->X, n, d, vt.p, m_pad, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0));  // R/GPCclass.R:112
-    GPRC_TRY(launch_row_reduce(s, vt.p, m_pad, m_pad, n_pad, m->alpha, mean_c, red.p));                      // :113
-    GPRC_TRY(launch_scale_cols(s, vt.p, m_pad, m_pad, n_pad, m->sw));                                         // sqrt(W) * K_star
-    GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt.p, m_pad));                                        // :114
-    GPRC_TRY(launch_row_reduce(s, vt.p, m_pad, m_pad, n_pad, nullptr, ss_c, red.p));
+    GPRC_TRY(launch_fill(s, m->ks, xc, mcur, m->X, n, d, vt.p, ldv, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0));  // R/GPCclass.R:112
+    GPRC_TRY(launch_row_reduce(s, vt.p, ldv, m_pad, n_pad, m->alpha, mean_c, red.p));                      // :113
+    GPRC_TRY(launch_scale_cols(s, vt.p, ldv, m_pad, n_pad, m->sw));                                         // sqrt(W) * K_star
+    GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt.p, ldv, m_pad));                                 // :114
+    GPRC_TRY(launch_row_reduce(s, vt.p, ldv, m_pad, n_pad, nullptr, ss_c, red.p));
     GPRC_TRY(launch_colwise(s, m->ks, xc, xc, d, mcur, kss_c));
     GPRC_TRY(launch_sub(s, kss_c, ss_c, vf.dev + s0, mcur));                                                  // :115
     GPRC_HIP(hipMemcpyAsync(fs.dev + s0, mean_c, sizeof(double) * mcur, hipMemcpyDeviceToDevice, s));
@@ -695,12 +737,13 @@ int gprc_dev_trsv(gprc_ctx* ctx, const double* packed, const double* winv, int64
 }
 
 int gprc_dev_fill_cross(gprc_ctx* ctx, int kernel, const double* params_host, int n_params, const double* X_star,
-                        int64_t d, int64_t m, int64_t m_pad, const double* X, int64_t n, int64_t n_pad, double* vt) {
+                        int64_t d, int64_t m, int64_t m_pad, const double* X, int64_t n, int64_t n_pad, double* vt,
+                        int64_t ld) {
   GPRC_TRY(use_device(ctx));
-  if (m_pad % 128 || m_pad < m || n_pad < n) { set_error("fill_cross: bad padding"); return GPRC_ERR_ARG; }
+  if (m_pad % 128 || m_pad < m || n_pad < n || ld < m_pad || ld % 2) { set_error("fill_cross: bad padding"); return GPRC_ERR_ARG; }
   KernelSpec ks;
   GPRC_TRY(make_spec(kernel, params_host, n_params, d, &ks));
-  return launch_fill(ctx->stream, ks, X_star, m, X, n, d, vt, m_pad, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0);
+  return launch_fill(ctx->stream, ks, X_star, m, X, n, d, vt, ld, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0);
 }
 
 int gprc_dev_row_reduce(gprc_ctx* ctx, const double* vt, int64_t ld, int64_t rows, int64_t cols, const double* w,
@@ -709,11 +752,62 @@ int gprc_dev_row_reduce(gprc_ctx* ctx, const double* vt, int64_t ld, int64_t row
   return launch_row_reduce(ctx->stream, vt, ld, rows, cols, w, out, work);
 }
 
-int gprc_dev_solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt,
-                        int64_t m_pad) {
+int gprc_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return 0;
+}
+int gprc_prof_reset(void) {
+  for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
+  g_prof_recs.clear();
+  return 0;
+}
+int gprc_prof_kinds(void) { return PK_COUNT; }
+int gprc_prof_summary(int kind, int64_t* count_out, double* ms_out, double* flops_out, double* bytes_out) {
+  if (kind < 0 || kind >= PK_COUNT) { set_error("prof_summary: bad kind"); return GPRC_ERR_ARG; }
+  int64_t cnt = 0;
+  double ms = 0.0, fl = 0.0, by = 0.0;
+  for (auto& r : g_prof_recs) {
+    if (r.kind != kind) continue;
+    GPRC_HIP(hipEventSynchronize(r.e1));
+    float t = 0.f;
+    GPRC_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
+    ms += t; fl += r.flops; by += r.bytes; ++cnt;
+  }
+  if (count_out) *count_out = cnt;
+  if (ms_out) *ms_out = ms;
+  if (flops_out) *flops_out = fl;
+  if (bytes_out) *bytes_out = by;
+  return 0;
+}
+
+int gprc_dev_logp(gprc_ctx* ctx, const double* packed, int64_t n_pad, int64_t n, const double* y, const double* alpha,
+                  double* out_dev) {
   GPRC_TRY(use_device(ctx));
-  if (m_pad % 128 || n_pad % NB) { set_error("solve_rows: bad padding"); return GPRC_ERR_ARG; }
-  return solve_rows(ctx, packed, winv, n_pad, vt, m_pad);
+  return launch_logp(ctx->stream, packed, n_pad, n, y, alpha, out_dev);
+}
+
+int gprc_gpr_model_from_device(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X,
+                               int64_t d, int64_t n, const double* y, double* packed, double* winv, double* alpha,
+                               double noise, double logp, gprc_model** model_out) {
+  GPRC_TRY(use_device(ctx));
+  if (!X || !y || !packed || !winv || !alpha || !model_out || d < 1 || n < 1) { set_error("model_from_device: bad arguments"); return GPRC_ERR_ARG; }
+  KernelSpec ks;
+  GPRC_TRY(make_spec(kernel, params, n_params, d, &ks));
+  gprc_model* m = new (std::nothrow) gprc_model();
+  if (!m) { set_error("out of host memory"); return GPRC_ERR_NOMEM; }
+  m->ctx = ctx; m->type = MODEL_GPR; m->ks = ks; m->n = n; m->d = d; m->n_pad = pad_up(n, NB);
+  m->borrowed = true;
+  m->X = const_cast<double*>(X); m->y = const_cast<double*>(y); m->packed = packed; m->winv = winv; m->alpha = alpha;
+  m->noise = noise; m->logp = logp;
+  *model_out = m;
+  return 0;
+}
+
+int gprc_dev_solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt,
+                        int64_t ld, int64_t m_pad) {
+  GPRC_TRY(use_device(ctx));
+  if (m_pad % 128 || n_pad % NB || ld < m_pad || ld % 2) { set_error("solve_rows: bad padding"); return GPRC_ERR_ARG; }
+  return solve_rows(ctx, packed, winv, n_pad, vt, ld, m_pad);
 }
 
 }  // extern "C"

@@ -10,9 +10,14 @@
 namespace gprc {
 
 // ---- geometry (DESIGN.md "Data layout") -------------------------------------------------------
-constexpr int NB = 512;   // outer panel width: K-depth of the trailing update (64 flop/B of C traffic)
+#ifndef GPRC_NB
+#define GPRC_NB 512
+#endif
+constexpr int NB = GPRC_NB;  // outer panel width: K-depth of the trailing update (NB/8 flop per byte of C traffic)
 constexpr int NBI = 128;  // inner block: one LDS-resident diagonal factorisation, one GEMM tile edge
+constexpr int TPP = NB / NBI;  // 128-wide tile columns per panel
 constexpr int MAX_PARAMS = 64;
+static_assert(NB % NBI == 0 && NB >= NBI, "panel width must be a multiple of the 128 block");
 
 __host__ __device__ static inline int64_t pad_up(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 __host__ __device__ static inline int64_t panel_offset(int64_t n_pad, int64_t p) { return (int64_t)NB * (p * n_pad - (int64_t)NB * p * (p - 1) / 2); }
@@ -33,6 +38,20 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     if (rc__ != 0) return rc__; \
   } while (0)
 #define GPRC_LAUNCH_CHECK() GPRC_HIP(hipGetLastError())
+
+// ---- in-library event profiler (bench.py's live roofline numbers) ---------------------------------
+enum ProfKind { PK_FILL = 0, PK_POTF2 = 1, PK_TRSM_PANEL = 2, PK_GEMM_INNER = 3, PK_TRAILING = 4, PK_SOLVE_UPDATE = 5,
+                PK_TRSV = 6, PK_ROWREDUCE = 7, PK_COV_SYRK = 8, PK_COUNT = 9 };
+bool prof_enabled();
+void prof_begin(hipStream_t s, int kind);
+void prof_end(hipStream_t s, int kind, double flops, double bytes);
+struct ProfScope {  // brackets one launch (or one launch sequence) with a pair of HIP events when profiling is on
+  hipStream_t s; int kind; double flops, bytes; bool on;
+  ProfScope(hipStream_t s_, int kind_, double flops_, double bytes_) : s(s_), kind(kind_), flops(flops_), bytes(bytes_), on(prof_enabled()) {
+    if (on) prof_begin(s, kind);
+  }
+  ~ProfScope() { if (on) prof_end(s, kind, flops, bytes); }
+};
 
 struct KernelSpec {
   int id;
@@ -59,7 +78,7 @@ int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* i
 int launch_trsm_panel(hipStream_t s, double* X, int64_t ldx, int64_t M, const double* winv);
 // C[M x N] -= A[M x K] * B[N x K]^T; lower_diag >= 0: row tile r / col tile c with r + lower_diag < c is skipped
 int launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
-                   int64_t M, int64_t N, int64_t K, int lower);
+                   int64_t M, int64_t N, int64_t K, int lower, int kind);
 // trailing update of packed panels q_begin, q_begin+q_stride, ... < q_end with factored panel p
 int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t p, int64_t q_begin, int64_t q_end,
                            int64_t q_stride);

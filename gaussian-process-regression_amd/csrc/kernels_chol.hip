@@ -93,10 +93,38 @@ constexpr int G_LDT = 144;
 constexpr int G_BUF = G_KB * G_LDT;           // doubles per operand per buffer
 constexpr int G_SMEM_DOUBLES = 4 * G_BUF;     // A,B x 2 buffers = 73,728 B -> 2 workgroups per CU
 
+// operands of one k-step (4 consecutive k) for this wave's 64x64 sub-tile: 4 A + 4 B doubles per lane
+__device__ __forceinline__ void read_ops(const double* Ac, const double* Bc, int kk, double (&a)[4], double (&b)[4]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) a[m] = Ac[kk * 4 * G_LDT + m * 16];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) b[n] = Bc[kk * 4 * G_LDT + n * 16];
+}
+__device__ __forceinline__ void mma_step(const double (&a)[4], const double (&b)[4], double4_t (&acc)[4][4]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[n], a[m], acc[m][n], 0, 0, 0);
+}
+
+// LDS-DMA of one k-tile of both strips: wave w moves k-slices w, w+4, w+8, w+12 of A and of B; one
+// global_load_lds_dwordx4 per slice = 64 lanes x 16 B = the slice's 128 rows, landing contiguously at a
+// wave-uniform LDS row (the 128-byte row pad survives because a row is exactly one instruction).
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ void dma_ktile(const double* Ag, int64_t lda, const double* Bg, int64_t ldb, double* Asb, double* Bsb) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(Ag + (int64_t)(4 * i) * lda), (lptr_t)(Asb + 4 * i * G_LDT), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(Bg + (int64_t)(4 * i) * ldb), (lptr_t)(Bsb + 4 * i * G_LDT), 16, 0, 0);
+  }
+}
+
 template <bool SET>
 __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                                               int64_t ldb, int K, double* smem) {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int fk = lane >> 4, fr = lane & 15;
   double* As = smem;
@@ -108,60 +136,46 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-  // staging: wave w moves k-slices w, w+4, w+8, w+12; lane l moves rows 2l, 2l+1 (16 B)
-  const double* Ag = A + 2 * lane + (int64_t)wave * lda;
+  const double* Ag = A + 2 * lane + (int64_t)wave * lda;  // this lane's 16 bytes of k-slice `wave`
   const double* Bg = B + 2 * lane + (int64_t)wave * ldb;
-  const int soff = wave * G_LDT + 2 * lane;
-  double2 ra[4], rb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    ra[i] = *reinterpret_cast<const double2*>(Ag + (int64_t)(4 * i) * lda);
-    rb[i] = *reinterpret_cast<const double2*>(Bg + (int64_t)(4 * i) * ldb);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<double2*>(As + soff + 4 * i * G_LDT) = ra[i];
-    *reinterpret_cast<double2*>(Bs + soff + 4 * i * G_LDT) = rb[i];
-  }
-  __syncthreads();
+  const int srow = wave * G_LDT;                          // LDS row of that slice (wave-uniform)
+  const int foff = fr + fk * G_LDT;                       // this lane's MFMA operand element
 
+  // Software pipeline.  Invariant at the top of iteration kt: tile kt is visible in buffer kt&1, the DMA
+  // of tile kt+1 is in flight into the other buffer, and a0/b0 hold the operands of (kt, k-step 0).
+  // The barrier sits in front of the LAST k-step's MFMAs: by then every wave holds its last operands of
+  // tile kt in registers, so the buffer can be handed to the DMA of tile kt+2 while 16 MFMAs still run,
+  // and that DMA has a full tile of MFMAs (64 x 64 cycles) to land.
   const int KT = K / G_KB;
-  int cur = 0;
+  dma_ktile(Ag, lda, Bg, ldb, As + srow, Bs + srow);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (KT > 1) dma_ktile(Ag + (int64_t)G_KB * lda, lda, Bg + (int64_t)G_KB * ldb, ldb, As + G_BUF + srow, Bs + G_BUF + srow);
+  Ag += (int64_t)2 * G_KB * lda;  // next tile to request: kt + 2
+  Bg += (int64_t)2 * G_KB * ldb;
+  double a0[4], b0[4], a1[4], b1[4];
+  read_ops(As + wr * 64 + foff, Bs + wc * 64 + foff, 0, a0, b0);
   for (int kt = 0; kt < KT; ++kt) {
-    const bool more = (kt + 1 < KT);
-    if (more) {
-      Ag += (int64_t)G_KB * lda;
-      Bg += (int64_t)G_KB * ldb;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const double2*>(Ag + (int64_t)(4 * i) * lda);
-        rb[i] = *reinterpret_cast<const double2*>(Bg + (int64_t)(4 * i) * ldb);
+    const int cur = (kt & 1) * G_BUF, nxt = G_BUF - cur;
+    const double* Ac = As + cur + wr * 64 + foff;
+    const double* Bc = Bs + cur + wc * 64 + foff;
+    read_ops(Ac, Bc, 1, a1, b1);
+    mma_step(a0, b0, acc);
+    read_ops(Ac, Bc, 2, a0, b0);
+    mma_step(a1, b1, acc);
+    read_ops(Ac, Bc, 3, a1, b1);
+    mma_step(a0, b0, acc);
+    if (kt + 1 < KT) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 has landed (this wave's share)
+      __syncthreads();                                   // ... everyone's share; and buffer `cur` is drained
+      if (kt + 2 < KT) {
+        dma_ktile(Ag, lda, Bg, ldb, As + cur + srow, Bs + cur + srow);
+        Ag += (int64_t)G_KB * lda;
+        Bg += (int64_t)G_KB * ldb;
       }
+      read_ops(As + nxt + wr * 64 + foff, Bs + nxt + wc * 64 + foff, 0, a0, b0);
     }
-    const double* Ac = As + cur * G_BUF + wr * 64 + fr + fk * G_LDT;
-    const double* Bc = Bs + cur * G_BUF + wc * 64 + fr + fk * G_LDT;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      double a[4], b[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) a[m] = Ac[kk * 4 * G_LDT + m * 16];
-#pragma unroll
-      for (int n = 0; n < 4; ++n) b[n] = Bc[kk * 4 * G_LDT + n * 16];
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[n], a[m], acc[m][n], 0, 0, 0);
-    }
-    if (more) {
-      const int nb = (cur ^ 1) * G_BUF;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<double2*>(As + nb + soff + 4 * i * G_LDT) = ra[i];
-        *reinterpret_cast<double2*>(Bs + nb + soff + 4 * i * G_LDT) = rb[i];
-      }
-    }
-    __syncthreads();
-    cur ^= 1;
+    mma_step(a1, b1, acc);
   }
 
   double* Cw = C + (wr * 64 + fr) + (int64_t)(wc * 64 + fk) * ldc;
@@ -183,7 +197,10 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-// C[M x N] -= A * B^T, 1-D grid of (M/128)*(N/128) tiles visited in 8-row groups
+// C[M x N] -= A * B^T, 1-D grid of (M/128)*(N/128) tiles visited in 8-row groups.  ROLE only gives
+// each use its own symbol (rocprof / event profiler tell them apart): in-panel update (K = 128),
+// predict-side right update (K = 512), posterior-covariance SYRK (K = n).
+template <int ROLE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc, const double* A, int64_t lda,
                                                          const double* B, int64_t ldb, int tiles_m, int tiles_n, int K,
                                                          int lower) {
@@ -214,21 +231,23 @@ __global__ __launch_bounds__(256, 2) void trailing_kernel(double* packed, int64_
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int P = (int)(n_pad / NB);
   int id = (int)xcd_remap(blockIdx.x, gridDim.x);
-  // locate the target panel: panel q holds 16*(P-q) - 6 lower tiles
+  // locate the target panel: panel q holds TPP*TPP*(P-q) - TPP*(TPP-1)/2 lower tiles
+  constexpr int DIAG_TILES = TPP * (TPP + 1) / 2;
   int q = q_begin, s = 0;
   for (; s < n_targets; ++s, q += q_stride) {
-    const int tq = 16 * (P - q) - 6;
+    const int tq = TPP * TPP * (P - q) - TPP * (TPP - 1) / 2;
     if (id < tq) break;
     id -= tq;
   }
   if (s >= n_targets) return;
   int tr, tc;
-  if (id < 10) {  // the diagonal 512x512 block: lower tiles (0,0) (1,0) (1,1) (2,0) ...
-    tr = (id >= 6) ? 3 : (id >= 3) ? 2 : (id >= 1) ? 1 : 0;
+  if (id < DIAG_TILES) {  // the diagonal NB x NB block: lower tiles (0,0) (1,0) (1,1) (2,0) ...
+    tr = 0;
+    while ((tr + 1) * (tr + 2) / 2 <= id) ++tr;
     tc = id - tr * (tr + 1) / 2;
   } else {
-    tr = 4 + ((id - 10) >> 2);
-    tc = (id - 10) & 3;
+    tr = TPP + (id - DIAG_TILES) / TPP;
+    tc = (id - DIAG_TILES) % TPP;
   }
   const int64_t ldp = panel_ld(n_pad, p), ldq = panel_ld(n_pad, q);
   const double* Lp = packed + panel_offset(n_pad, p) + (int64_t)(q - p) * NB;  // row q*NB of panel p
@@ -246,6 +265,7 @@ int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* i
     GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
+  ProfScope ps(s, PK_POTF2, 128.0 * 128 * 128 / 3 * 2, 8.0 * 3 * 128 * 128);
   hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(1024), smem, s, A, lda, winv, info_dev, col0);
   GPRC_LAUNCH_CHECK();
   return 0;
@@ -255,7 +275,9 @@ static int ensure_gemm_attrs() {
   static bool done = false;
   if (done) return 0;
   const int smem = (int)(G_SMEM_DOUBLES * sizeof(double));
-  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<PK_GEMM_INNER>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<PK_SOLVE_UPDATE>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<PK_COV_SYRK>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   done = true;
@@ -266,20 +288,27 @@ int launch_trsm_panel(hipStream_t s, double* X, int64_t ldx, int64_t M, const do
   if (M <= 0) return 0;
   if (M % 128) { set_error("trsm_panel: M must be a multiple of 128"); return GPRC_ERR_ARG; }
   GPRC_TRY(ensure_gemm_attrs());
+  ProfScope ps(s, PK_TRSM_PANEL, 1.0 * M * 128 * 128, 8.0 * 2 * M * 128);
   hipLaunchKernelGGL(trsm_panel_kernel, dim3((unsigned)(M / 128)), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, X, ldx, winv);
   GPRC_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
-                   int64_t M, int64_t N, int64_t K, int lower) {
+                   int64_t M, int64_t N, int64_t K, int lower, int kind) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if (M % 128 || N % 128 || K % G_KB || (lda & 1) || (ldb & 1)) { set_error("gemm_nt: bad shape"); return GPRC_ERR_ARG; }
   GPRC_TRY(ensure_gemm_attrs());
   const int64_t tiles = (M / 128) * (N / 128);
   if (tiles > 0x7fffffff) { set_error("gemm_nt: too many tiles"); return GPRC_ERR_ARG; }
-  hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)tiles), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, C, ldc, A, lda, B,
-                     ldb, (int)(M / 128), (int)(N / 128), (int)K, lower);
+  const double useful = lower ? 0.5 : 1.0;  // algorithmic: the lower triangle only
+  ProfScope ps(s, kind, 2.0 * M * N * K * useful, 8.0 * (2.0 * M * N * useful + (M + N) * (double)K));
+  const dim3 grid((unsigned)tiles), block(256);
+  const size_t smem = G_SMEM_DOUBLES * sizeof(double);
+  const int tm = (int)(M / 128), tn = (int)(N / 128);
+  if (kind == PK_SOLVE_UPDATE) hipLaunchKernelGGL((gemm_nt_kernel<PK_SOLVE_UPDATE>), grid, block, smem, s, C, ldc, A, lda, B, ldb, tm, tn, (int)K, lower);
+  else if (kind == PK_COV_SYRK) hipLaunchKernelGGL((gemm_nt_kernel<PK_COV_SYRK>), grid, block, smem, s, C, ldc, A, lda, B, ldb, tm, tn, (int)K, lower);
+  else hipLaunchKernelGGL((gemm_nt_kernel<PK_GEMM_INNER>), grid, block, smem, s, C, ldc, A, lda, B, ldb, tm, tn, (int)K, lower);
   GPRC_LAUNCH_CHECK();
   return 0;
 }
@@ -290,9 +319,17 @@ int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t
   if (q_begin <= p || q_stride <= 0) { set_error("trailing_update: bad panel range"); return GPRC_ERR_ARG; }
   if (q_end > P) q_end = P;
   int64_t tiles = 0, nt = 0;
-  for (int64_t q = q_begin; q < q_end; q += q_stride) { tiles += 16 * (P - q) - 6; ++nt; }
+  for (int64_t q = q_begin; q < q_end; q += q_stride) { tiles += (int64_t)TPP * TPP * (P - q) - TPP * (TPP - 1) / 2; ++nt; }
   if (tiles == 0) return 0;
   GPRC_TRY(ensure_gemm_attrs());
+  double fl = 0.0, by = 0.0;  // algorithmic: lower triangle of the 512-wide diagonal block + everything below it
+  for (int64_t q = q_begin; q < q_end; q += q_stride) {
+    const double rows = (double)(n_pad - q * NB);
+    const double elems = rows * NB - 0.5 * NB * (double)(NB - 1);
+    fl += 2.0 * elems * NB;
+    by += 8.0 * (2.0 * elems + rows * NB);
+  }
+  ProfScope ps(s, PK_TRAILING, fl, by);
   hipLaunchKernelGGL(trailing_kernel, dim3((unsigned)tiles), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)p,
                      (int)q_begin, (int)q_stride, (int)nt);
   GPRC_LAUNCH_CHECK();

@@ -156,6 +156,7 @@ int launch_fill(hipStream_t s, const KernelSpec& ks, const double* A, int64_t nA
   if (nrows <= 0 || ncols <= 0) return 0;
   if ((ncols + FT_C - 1) / FT_C > 65535) { set_error("fill: too many column tiles in one launch"); return GPRC_ERR_ARG; }
   FillArgs a{A, B, out, nA, nB, d, ld, row0, nrows, col0, ncols, (int)mode, noise, ks};
+  ProfScope ps(s, PK_FILL, (double)nrows * ncols * (3.0 * d + 20.0), 8.0 * nrows * ncols);
   switch (ks.id) {
     case GPRC_CONSTANT: return do_fill<GPRC_CONSTANT>(s, a);
     case GPRC_LINEAR: return do_fill<GPRC_LINEAR>(s, a);

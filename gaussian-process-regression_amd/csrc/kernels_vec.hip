@@ -248,6 +248,7 @@ int64_t rowreduce_splits(int64_t cols) { return (cols + RR_COLS - 1) / RR_COLS; 
 
 int launch_trsv(hipStream_t s, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose, double* work) {
   const int nblk = (int)(n_pad / 128);
+  ProfScope ps(s, PK_TRSV, (double)n_pad * n_pad, 8.0 * 0.5 * n_pad * n_pad);
   if (!transpose) {
     hipLaunchKernelGGL(trsv_fwd_first, dim3(1), dim3(128), 0, s, winv, b);
     for (int blk = 0; blk + 1 < nblk; ++blk)
@@ -270,6 +271,7 @@ int launch_row_reduce(hipStream_t s, const double* vt, int64_t ld, int64_t rows,
   if (rows % 128) { set_error("row_reduce: rows must be a multiple of 128"); return GPRC_ERR_ARG; }
   const int64_t splits = rowreduce_splits(cols);
   if (splits > 65535) { set_error("row_reduce: too many column splits"); return GPRC_ERR_ARG; }
+  ProfScope ps(s, PK_ROWREDUCE, 2.0 * rows * cols, 8.0 * rows * cols);
   hipLaunchKernelGGL(row_reduce_partial, dim3((unsigned)(rows / 128), (unsigned)splits), dim3(128), 0, s, vt, ld, cols, w, work, rows);
   hipLaunchKernelGGL(row_reduce_final, dim3(blocks(rows, 256)), dim3(256), 0, s, work, rows, (int)splits, out);
   GPRC_LAUNCH_CHECK();

@@ -1,0 +1,299 @@
+"""One-process-per-GPU driver of the GP predict step (fit + predict) over torch.distributed.
+
+Sharding (DESIGN.md "Multi-GPU"):
+  * the factor lives in the packed block-column layout; panel p (512 columns, contiguous in memory) is
+    OWNED by rank p mod G (1-D block-cyclic).  Every rank allocates the whole packed buffer: it fills
+    and updates only its own panels and RECEIVES the others, so after the factorisation L is
+    replicated (17 GB at n = 65536, of 288 GB) and the predict needs no communication;
+  * the one exchange step of the path: the owner broadcasts the factored panel (+ the inverses of its
+    four diagonal blocks) -- RCCL broadcast over xGMI on the GPU box, gloo in the CPU tests;
+  * look-ahead: the owner of panel p+1 updates and factors that panel on a side stream while the
+    rest of trailing update p is still running on the main stream, and every rank posts the receive
+    of panel p+1 on its side stream at the same point, so the broadcast overlaps the update;
+  * alpha is solved redundantly on every rank; the n* test points are split in contiguous slices.
+
+The arithmetic is behind an `ops` object.  `HipOps` (below) is the product: native HIP kernels through
+the C ABI on torch-owned device memory.  The CPU tests inject an oracle-backed ops object of the same
+shape from tests/ -- nothing in this package falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from contextlib import contextmanager
+
+import numpy as np
+
+from . import _native as nat
+
+
+class Geometry:
+    """Packed block-column geometry of an n x n factor (pure index arithmetic from the C ABI)."""
+
+    def __init__(self, n: int):
+        L = nat.lib()
+        self.n = int(n)
+        self.NB = int(L.gprc_panel_width())
+        self.n_pad = int(L.gprc_pad(n))
+        self.P = int(L.gprc_panel_count(self.n_pad))
+        self.offsets = [int(L.gprc_panel_offset(self.n_pad, p)) for p in range(self.P + 1)]
+        self.packed_size = int(L.gprc_packed_size(self.n_pad))
+        self.winv_size = int(L.gprc_winv_size(self.n_pad))
+        self.winv_per_panel = self.winv_size // self.P
+        self.trsv_work = int(L.gprc_trsv_work_size(self.n_pad))
+
+    def panel_slice(self, p):
+        return slice(self.offsets[p], self.offsets[p + 1])
+
+    def winv_slice(self, p):
+        return slice(p * self.winv_per_panel, (p + 1) * self.winv_per_panel)
+
+
+class SingleComm:
+    """world_size 1: no exchange."""
+    rank, world = 0, 1
+
+    def broadcast(self, t, src):
+        pass
+
+    def min_positive(self, value: int) -> int:
+        return value
+
+    def gather_concat(self, t, sizes):
+        return t
+
+    def barrier(self):
+        pass
+
+
+class TorchComm:
+    """torch.distributed (backend nccl == RCCL on ROCm; gloo on CPU)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def broadcast(self, t, src):
+        self.dist.broadcast(t, src=src)
+
+    def min_positive(self, value: int) -> int:
+        import torch
+        big = 2 ** 62
+        t = torch.tensor([value if value > 0 else big], dtype=torch.int64)
+        if self.dist.get_backend() == "nccl":
+            t = t.cuda()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        v = int(t.item())
+        return 0 if v == big else v
+
+    def gather_concat(self, t, sizes):
+        """All ranks contribute a 1-D tensor (rank r: sizes[r] valid entries); returns the concatenation."""
+        import torch
+        m = max(sizes)
+        buf = torch.zeros(m, dtype=t.dtype, device=t.device)
+        buf[: t.numel()] = t
+        outs = [torch.empty_like(buf) for _ in range(self.world)]
+        self.dist.all_gather(outs, buf)
+        return torch.cat([o[:s] for o, s in zip(outs, sizes)])
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+class HipOps:
+    """Native stage launcher on one GPU: torch owns memory and streams, the C ABI does the arithmetic."""
+
+    def __init__(self, device: int, kernel_id: int, params, d: int, n: int, noise: float):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.main_stream = torch.cuda.Stream(device=self.device)
+        self.side_stream = torch.cuda.Stream(device=self.device)
+        self.ctx_main = nat.Context(device, self.main_stream.cuda_stream)
+        self.ctx_side = nat.Context(device, self.side_stream.cuda_stream)
+        self.kernel_id = int(kernel_id)
+        self.params, self._pp, self._np = nat.params_array(params)
+        self.d, self.n, self.noise = int(d), int(n), float(noise)
+        self.geom = Geometry(n)
+        self.L = nat.lib()
+
+    # ---- memory ----
+    def zeros(self, count, dtype=None):
+        with self.torch.cuda.stream(self.main_stream):
+            return self.torch.zeros(int(count), dtype=dtype or self.torch.float64, device=self.device)
+
+    def from_host(self, a):
+        with self.torch.cuda.stream(self.main_stream):
+            return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def to_host(self, t):
+        self.synchronize()
+        return t.cpu().numpy()
+
+    # ---- streams ----
+    @contextmanager
+    def on(self, side: bool):
+        with self.torch.cuda.stream(self.side_stream if side else self.main_stream):
+            yield
+
+    def fork_side(self):
+        self.side_stream.wait_stream(self.main_stream)
+
+    def join_side(self):
+        self.main_stream.wait_stream(self.side_stream)
+
+    def synchronize(self):
+        self.main_stream.synchronize()
+        self.side_stream.synchronize()
+
+    def _ctx(self, side):
+        return (self.ctx_side if side else self.ctx_main).handle
+
+    # ---- stages ----
+    def fill_panel(self, X, packed, p):
+        g = self.geom
+        nat.check(self.L.gprc_dev_fill_panel(self._ctx(False), self.kernel_id, self._pp, self._np, X.data_ptr(), self.d, self.n, g.n_pad,
+                                             self.noise, packed.data_ptr(), p))
+
+    def factor_panel(self, packed, p, winv, info, side):
+        nat.check(self.L.gprc_dev_factor_panel(self._ctx(side), packed.data_ptr(), self.geom.n_pad, p, winv.data_ptr(), info.data_ptr()))
+
+    def update_trailing(self, packed, p, q0, q1, stride, side):
+        if q0 < q1:
+            nat.check(self.L.gprc_dev_update_trailing(self._ctx(side), packed.data_ptr(), self.geom.n_pad, p, q0, q1, stride))
+
+    def trsv(self, packed, winv, b, transpose, work):
+        nat.check(self.L.gprc_dev_trsv(self._ctx(False), packed.data_ptr(), winv.data_ptr(), self.geom.n_pad, b.data_ptr(), int(transpose),
+                                       work.data_ptr()))
+
+    def logp(self, packed, y, alpha, out):
+        nat.check(self.L.gprc_dev_logp(self._ctx(False), packed.data_ptr(), self.geom.n_pad, self.n, y.data_ptr(), alpha.data_ptr(),
+                                       out.data_ptr()))
+
+    def read_info(self, info) -> int:
+        self.synchronize()
+        return int(info[0].item())
+
+    def predict(self, X, y, packed, winv, alpha, Xs, ns, mean, var):
+        """Pointwise predict of `ns` test points (device buffers) against the replicated factor."""
+        if ns == 0:
+            return
+        model = C.c_void_p()
+        nat.check(self.L.gprc_gpr_model_from_device(self._ctx(False), self.kernel_id, self._pp, self._np, X.data_ptr(), self.d, self.n,
+                                                    y.data_ptr(), packed.data_ptr(), winv.data_ptr(), alpha.data_ptr(), self.noise, 0.0,
+                                                    C.byref(model)))
+        try:
+            nat.check(self.L.gprc_gpr_predict(model, Xs.data_ptr(), ns, 1, mean.data_ptr(), var.data_ptr()))
+        finally:
+            self.L.gprc_model_free(model)
+
+    def close(self):
+        self.synchronize()
+        self.ctx_main.close()
+        self.ctx_side.close()
+
+
+def owned_after(p: int, rank: int, world: int) -> int:
+    """Smallest panel index q > p with q mod world == rank."""
+    q = p + 1
+    return q + (rank - q) % world
+
+
+class DistributedGPR:
+    """The predict step of BASELINE.json on G ranks: fit (F1-F3) + pointwise predict (P1-P3)."""
+
+    def __init__(self, ops, comm, lookahead=None):
+        import os
+        self.ops, self.comm = ops, comm
+        # GPRC_NO_LOOKAHEAD=1 serialises the panel factorisation behind the trailing update (measurement aid)
+        self.lookahead = (os.environ.get("GPRC_NO_LOOKAHEAD", "0") != "1") if lookahead is None else bool(lookahead)
+        g = ops.geom
+        self.geom = g
+        self.packed = ops.zeros(g.packed_size)
+        self.winv = ops.zeros(g.winv_size)
+        self.alpha = ops.zeros(g.n_pad)
+        self.work = ops.zeros(g.trsv_work)
+        self.info = ops.zeros(4, dtype=_int32(ops))
+        self.scal = ops.zeros(8)
+        self.logp = None
+        self.info_value = 0
+
+    # -- F1 + F2 + F3 ------------------------------------------------------------------------------
+    def fit(self, X, y_pad):
+        """X: d x n device buffer (point-major); y_pad: n_pad doubles, zero padded.  Returns LAPACK info."""
+        ops, comm, g = self.ops, self.comm, self.geom
+        rank, G, P = comm.rank, comm.world, g.P
+        with ops.on(False):
+            self.info.zero_() if hasattr(self.info, "zero_") else self.info.fill(0)
+            for p in range(rank, P, G):                       # F1: own panels only, no communication
+                ops.fill_panel(X, self.packed, p)
+        ops.fork_side()
+        if rank == 0:
+            with ops.on(True):
+                ops.factor_panel(self.packed, 0, self.winv, self.info, True)
+        self._bcast_panel(0)
+        for p in range(P):                                    # F2: right-looking, one panel per step
+            ops.join_side()                                   # panel p factored (owner) / received (others)
+            if p + 1 < P:
+                nxt = (p + 1) % G
+                if rank == nxt and not self.lookahead:
+                    with ops.on(False):
+                        ops.update_trailing(self.packed, p, p + 1, P, G, False)
+                    ops.fork_side()
+                    with ops.on(True):
+                        ops.factor_panel(self.packed, p + 1, self.winv, self.info, True)
+                    self._bcast_panel(p + 1)
+                    continue
+                if rank == nxt:
+                    ops.fork_side()                           # look-ahead: panel p+1 first, on the side stream
+                    with ops.on(True):
+                        ops.update_trailing(self.packed, p, p + 1, p + 2, 1, True)
+                        ops.factor_panel(self.packed, p + 1, self.winv, self.info, True)
+                    q0 = p + 1 + G
+                else:
+                    q0 = owned_after(p, rank, G)
+                with ops.on(False):
+                    ops.update_trailing(self.packed, p, q0, P, G, False)
+                self._bcast_panel(p + 1)                      # overlaps the update above
+        ops.join_side()
+        self.info_value = comm.min_positive(ops.read_info(self.info))
+        if self.info_value != 0:
+            return self.info_value
+        with ops.on(False):                                   # F3: replicated, L is complete everywhere
+            _copy(self.alpha, y_pad)
+            ops.trsv(self.packed, self.winv, self.alpha, False, self.work)
+            ops.trsv(self.packed, self.winv, self.alpha, True, self.work)
+            ops.logp(self.packed, y_pad, self.alpha, self.scal)
+        return 0
+
+    def _bcast_panel(self, p):
+        if self.comm.world == 1:
+            return
+        g = self.geom
+        src = p % self.comm.world
+        with self.ops.on(True):
+            self.comm.broadcast(self.packed[g.panel_slice(p)], src)
+            self.comm.broadcast(self.winv[g.winv_slice(p)], src)
+
+    # -- P1 + P2 + P3 ------------------------------------------------------------------------------
+    @staticmethod
+    def slice_bounds(ns: int, world: int):
+        per = -(-ns // world)
+        return [(min(r * per, ns), min((r + 1) * per, ns)) for r in range(world)]
+
+    def predict_local(self, X, y_pad, Xs_local, ns_local, mean_local, var_local):
+        with self.ops.on(False):
+            self.ops.predict(X, y_pad, self.packed, self.winv, self.alpha, Xs_local, ns_local, mean_local, var_local)
+
+
+def _int32(ops):
+    t = getattr(ops, "torch", None)
+    return t.int32 if t is not None else np.int32
+
+
+def _copy(dst, src):
+    if hasattr(dst, "copy_"):
+        dst.copy_(src)
+    else:
+        dst[...] = src

@@ -5,8 +5,11 @@ iteration B = I + sqrt(W) K sqrt(W), its Cholesky, two triangular solves and two
 `predict_class` gets fs_bar / Vfs from the GPU (R/GPCclass.R:109-115) and then evaluates the
 reference's per-point 1-D integral (:116-117) on the host with QUADPACK, as the reference does with
 stats::integrate -- that integral is the caller of the hot path (SURVEY 8f), not part of it.
-Reference quirks are reproduced: logq uses sum(diag(L)) (:103), and the integral passes the
-*variance* Vfs as dnorm's sd (:117).
+Reference quirks are reproduced: logq uses sum(diag(L)) (:103), the integral passes the *variance* Vfs
+as dnorm's sd (:117), and the stop rule of :90-91 (`least_objective + 10 < objective`, which fires when
+the maximised objective IMPROVES by more than 10 over iteration 1) raises "Apparently does not converge."
+exactly where the reference does.  `reference_stop=False` (keyword-only, not in the reference) switches
+that rule off so that larger problems can be fitted.
 """
 from __future__ import annotations
 
@@ -25,7 +28,7 @@ __all__ = ["GPC"]
 class GPC:
     """GPC$new(X, y, k, epsilon = 1e-5)  --  R/GPCclass.R:66."""
 
-    def __init__(self, X, y, k, epsilon=1e-5, *, ctx=None, max_iter=0):
+    def __init__(self, X, y, k, epsilon=1e-5, *, ctx=None, max_iter=0, reference_stop=True):
         Xa = np.asarray(X)
         if Xa.dtype.kind not in "fiub" or not _is_numeric_vector(y):
             raise TypeError("is.numeric(X), is.vector(y), is.numeric(y) are not all TRUE")        # :67
@@ -44,7 +47,8 @@ class GPC:
         _, pp, npar = nat.params_array(k.native_params(d))
         iters = C.c_int()
         rc = nat.lib().gprc_gpc_fit(self._ctx.handle, k.gprc_kernel[0], pp, npar, Xm.ctypes.data, d, n, y.ctypes.data,
-                                    float(epsilon), int(max_iter), C.byref(self._model), C.byref(iters))
+                                    float(epsilon), int(max_iter), nat.GPC_REFERENCE_STOP if reference_stop else 0,
+                                    C.byref(self._model), C.byref(iters))
         if rc == nat.ERR_DIVERGED:
             raise ArithmeticError("Apparently does not converge.")                               # :91
         nat.check(rc)

@@ -117,9 +117,15 @@ GPRC_API int gprc_model_free(gprc_model* model);
 
 /* ---- L2: GPC ------------------------------------------------------------------------------ */
 /* GPC$initialize (R/GPCclass.R:66-107): Laplace mode by Newton/IRLS; y in {-1,+1}.
- * max_iter <= 0 selects 1000.  *iters_out = the "Convergence after %s iterations" count (:98). */
+ * max_iter <= 0 selects 1000.  *iters_out = the "Convergence after %s iterations" count (:98).
+ * flags: GPRC_GPC_REFERENCE_STOP reproduces the reference's stop rule of :90-91 verbatim
+ * (`least_objective + 10 < objective` -> GPRC_ERR_DIVERGED; note it fires whenever the maximised objective
+ * IMPROVES by more than 10 over iteration 1, i.e. for most problems beyond a few hundred points);
+ * 0 switches that rule off and iterates to |delta objective| < epsilon. */
+#define GPRC_GPC_REFERENCE_STOP 1
 GPRC_API int gprc_gpc_fit(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d,
-                 int64_t n, const double* y, double epsilon, int max_iter, gprc_model** model_out, int* iters_out);
+                 int64_t n, const double* y, double epsilon, int max_iter, int flags, gprc_model** model_out,
+                 int* iters_out);
 /* the hot part of GPC$predict_class (R/GPCclass.R:109-115): fs_bar and Vfs for X_star. */
 GPRC_API int gprc_gpc_predict_latent(gprc_model* model, const double* X_star, int64_t n_star, double* fs_bar_out,
                             double* Vfs_out);
@@ -153,16 +159,38 @@ GPRC_API int gprc_dev_update_trailing(gprc_ctx* ctx, double* packed, int64_t n_p
 GPRC_API int64_t gprc_trsv_work_size(int64_t n_pad);
 GPRC_API int gprc_dev_trsv(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose,
                   double* work);
-/* vt (m_pad x n_pad, ld = m_pad, m_pad % 128 == 0) = K(X_star, X), zero in the padding */
+/* vt (m_pad x n_pad, leading dimension ld >= m_pad, ld even, m_pad % 128 == 0) = K(X_star, X), zero in the
+ * padding.  Keep ld off powers of two (e.g. m_pad + 128): a 2^k-byte column stride aliases HBM channels. */
 GPRC_API int gprc_dev_fill_cross(gprc_ctx* ctx, int kernel, const double* params_host, int n_params, const double* X_star,
-                        int64_t d, int64_t m, int64_t m_pad, const double* X, int64_t n, int64_t n_pad, double* vt);
+                        int64_t d, int64_t m, int64_t m_pad, const double* X, int64_t n, int64_t n_pad, double* vt,
+                        int64_t ld);
 /* out[i] = sum_j vt[i + j*ld] * w[j]  (w == NULL: sum_j vt[i,j]^2); work: rows * gprc_rowreduce_splits(cols) */
 GPRC_API int64_t gprc_rowreduce_splits(int64_t cols);
 GPRC_API int gprc_dev_row_reduce(gprc_ctx* ctx, const double* vt, int64_t ld, int64_t rows, int64_t cols, const double* w,
                         double* out, double* work);
+/* out_dev[0] = -0.5 y.alpha - sum(log(diag L)) - n/2 log(2 pi)  (R/GPRclass.R:153) */
+GPRC_API int gprc_dev_logp(gprc_ctx* ctx, const double* packed, int64_t n_pad, int64_t n, const double* y, const double* alpha,
+                  double* out_dev);
+/* Wrap device buffers a driver factored itself (multi-GPU: every rank ends up with the full packed L,
+ * winv and alpha) into a model handle so gprc_gpr_predict() can run on this rank's slice of X_star.
+ * Nothing is copied or computed; the buffers are BORROWED and must outlive the handle.
+ * y and alpha hold n_pad doubles (zero padded). */
+GPRC_API int gprc_gpr_model_from_device(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X,
+                               int64_t d, int64_t n, const double* y, double* packed, double* winv, double* alpha,
+                               double noise, double logp, gprc_model** model_out);
 /* vt := vt * L^-T  (row i becomes (L^-1 k_i)^T) */
 GPRC_API int gprc_dev_solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt,
-                        int64_t m_pad);
+                        int64_t ld, int64_t m_pad);
+
+/* ---- measurement: per-kernel-kind HIP-event timing (bench.py's live roofline numbers) ------------ *
+ * When enabled, every launch is bracketed by two hipEvents on the stream it is launched on.  Kinds:
+ * 0 fill, 1 potf2_inv, 2 trsm_panel, 3 in-panel GEMM (K=128), 4 trailing update, 5 predict right
+ * update (K=512), 6 trsv, 7 row reductions, 8 covariance SYRK.  flops/bytes are the ALGORITHMIC
+ * figures of DESIGN.md for the launches seen, not counter readings. */
+GPRC_API int gprc_prof_enable(int on);
+GPRC_API int gprc_prof_reset(void);
+GPRC_API int gprc_prof_kinds(void);
+GPRC_API int gprc_prof_summary(int kind, int64_t* count_out, double* ms_out, double* flops_out, double* bytes_out);
 
 #ifdef __cplusplus
 }

@@ -296,10 +296,13 @@ static int gpc_chol_B(const double* K, const double* W, int64_t n, double* L) {
 /* a8: GPC$initialize (R/GPCclass.R:66-107): Laplace mode by Newton/IRLS, labels y in {-1,+1}.
  * Returns 0 ok; 2 = "Apparently does not converge." (:90-91); 3 = chol failed; 4 = max_iter hit
  * (the reference loops forever; max_iter is a safety net of this restatement).
- * Reference quirk kept: logq = objective - sum(diag(L)) (NOT log), :103. */
+ * Reference quirks kept: logq = objective - sum(diag(L)) (NOT log), :103; and the stop rule of :90 --
+ * `least_objective + 10 < objective`, where least_objective is the objective of iteration 1 and the
+ * objective is being MAXIMISED -- fires whenever Newton improves the objective by more than 10, i.e. for
+ * any sizeable n.  divergence_stop = 1 reproduces it (the reference's behaviour); 0 switches it off. */
 ORACLE_API int oracle_gpc_fit(int id, const double* par, int npar, const double* X, int64_t d, int64_t n,
-                              const double* y, double epsilon, int max_iter, double* f_hat, double* L, double* logq,
-                              int* iters) {
+                              const double* y, double epsilon, int max_iter, int divergence_stop, double* f_hat, double* L,
+                              double* logq, int* iters) {
   if (!check_params(id, npar, d)) return -1;
   double* K = (double*)malloc(sizeof(double) * n * n);
   double* w = (double*)malloc(sizeof(double) * n * 6);
@@ -343,7 +346,7 @@ ORACLE_API int oracle_gpc_fit(int id, const double* par, int npar, const double*
     objective = -saf / 2.0 - sll;
     if (it > 1) {
       if (fabs(objective - last_objective) < epsilon) break;          /* :88 */
-      else if (least_objective + 10.0 < objective) { rc = 2; break; } /* :90 */
+      else if (divergence_stop && least_objective + 10.0 < objective) { rc = 2; break; } /* :90 */
     } else {
       least_objective = objective;
     }

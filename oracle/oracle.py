@@ -145,7 +145,7 @@ def gpr_predict(kid, params, X, L, alpha, Xs, pointwise=True):
     return mean, var
 
 
-def gpc_fit(kid, params, X, y, epsilon=1e-5, max_iter=1000):
+def gpc_fit(kid, params, X, y, epsilon=1e-5, max_iter=1000, divergence_stop=True):
     X = _as_points(X)
     d, n = X.shape
     y = np.ascontiguousarray(np.asarray(y, dtype=np.float64))
@@ -155,7 +155,7 @@ def gpc_fit(kid, params, X, y, epsilon=1e-5, max_iter=1000):
     iters = C.c_int()
     p, pp, npar = _par(params)
     rc = lib().oracle_gpc_fit(C.c_int(kid), pp, npar, _p(X), _i64(d), _i64(n), _p(y), C.c_double(epsilon), C.c_int(max_iter),
-                              _p(f_hat), _p(L), C.byref(logq), C.byref(iters))
+                              C.c_int(1 if divergence_stop else 0), _p(f_hat), _p(L), C.byref(logq), C.byref(iters))
     if rc == 2:
         raise ArithmeticError("Apparently does not converge.")
     if rc:

@@ -1,0 +1,66 @@
+"""The C-ABI shared library loads on a CPU-only box, exports every symbol include/gprc_native.h declares,
+and the Python binding covers exactly that set.  No compute calls are made here."""
+import ctypes
+import os
+import re
+import subprocess
+
+from conftest import ROOT
+from gprc_amd import _native as nat
+
+HEADER = os.path.join(ROOT, "include", "gprc_native.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    return sorted(set(re.findall(r"GPRC_API\s+[A-Za-z_0-9\*\s]+?\b(gprc_[A-Za-z_0-9]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_surface():
+    syms = declared_symbols()
+    assert len(syms) >= 40
+    for must in ("gprc_kernel_matrix", "gprc_kernel_colwise", "gprc_gpr_fit", "gprc_gpr_fit_retry", "gprc_gpr_predict",
+                 "gprc_model_get_L", "gprc_gpc_fit", "gprc_gpc_predict_latent", "gprc_dev_factor_panel",
+                 "gprc_dev_update_trailing", "gprc_last_error"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(nat.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_binding_covers_exactly_the_header():
+    assert sorted(nat.PROTOTYPES) == declared_symbols()
+
+
+def test_no_stray_exports():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", nat.LIB_PATH], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if " T " in line and "gprc_" in line.split()[-1] and not line.split()[-1].startswith("_Z"))
+    assert exported == declared_symbols()
+
+
+def test_abi_version_and_error_string():
+    lib = nat.lib()
+    assert lib.gprc_abi_version() == 1
+    assert isinstance(nat.last_error(), str)
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "gprc_native.h"\nint main(void) { gprc_ctx* c = 0; gprc_model* m = 0; (void)c; (void)m; return GPRC_ABI_VERSION - 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+def test_product_never_touches_the_oracle():
+    """The package must not import, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "gaussian-process-regression_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh", ".cpp", ".c")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "liboracle" not in text and "gprc_oracle" not in text, f
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
+    out = subprocess.check_output(["ldd", nat.LIB_PATH], text=True)
+    assert "oracle" not in out

@@ -1,0 +1,74 @@
+"""Parity at BASELINE.json's full single-GPU sizes, where the CPU oracle would take minutes: size-independent
+identities of the posterior, plus an independent fp64 reference built from vendor LAPACK on the GPU
+(torch.linalg -- a floating-point kernel, so a torch fp64 reference is the allowed second opinion)."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import TOL, nerr
+from gprc_amd import GPR, cov_func, sqrexp, rationalquadratic
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _inputs(n, d, ns, seed=20261004):
+    rng = np.random.Generator(np.random.Philox(seed))
+    X = rng.uniform(-1, 1, (d, n))
+    y = 0.1 * (X ** 3).sum(0) + rng.normal(0, 0.1, n)
+    Xs = rng.uniform(-1, 1, (d, ns))
+    return X, y, Xs
+
+
+def _torch_reference(kind, X, y, Xs, noise):
+    dev = torch.device("cuda:0")
+    Xt, yt, Xst = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (X.T, y, Xs.T))
+
+    def kern(A, B):
+        D = torch.zeros(A.shape[0], B.shape[0], dtype=torch.float64, device=dev)
+        for r in range(A.shape[1]):                       # direct sum (x - y)^2, no Gram trick
+            D += (A[:, r, None] - B[None, :, r]) ** 2
+        return torch.exp(-D / 2) if kind == "sqrexp" else (1 + D / (2 * 1.5)) ** (-1.5)
+
+    n = Xt.shape[0]
+    K = kern(Xt, Xt) + noise * torch.eye(n, dtype=torch.float64, device=dev)
+    L = torch.linalg.cholesky(K)
+    alpha = torch.cholesky_solve(yt[:, None], L)[:, 0]
+    Ks = kern(Xt, Xst)
+    v = torch.linalg.solve_triangular(L, Ks, upper=False)
+    mean = Ks.T @ alpha
+    var = 1.0 - (v * v).sum(0)
+    logp = -0.5 * (yt @ alpha) - torch.log(torch.diagonal(L)).sum() - n / 2 * math.log(2 * math.pi)
+    return alpha.cpu().numpy(), float(logp), mean.cpu().numpy(), var.cpu().numpy()
+
+
+@pytest.mark.parametrize("kind,n,ns", [("sqrexp", 8192, 4096), ("rationalquadratic", 4096, 2048)])
+def test_full_size_against_vendor_lapack(kind, n, ns):
+    """BASELINE config 2 (n = 8192, d = 8, sqexp) and a rational-quadratic case (config 3's kernel)."""
+    d, noise = 8, 0.1
+    X, y, Xs = _inputs(n, d, ns)
+    k = cov_func(sqrexp, l=1.0) if kind == "sqrexp" else cov_func(rationalquadratic, l=1.0, alpha=1.5)
+    g = GPR(X, y, noise, k)
+    pr = g.predict(Xs)
+    alpha, logp, mean, var = _torch_reference(kind, X, y, Xs, noise)
+    assert nerr(g.alpha, alpha) <= TOL
+    assert abs(g.logp - logp) <= TOL * abs(logp)
+    assert nerr(pr[:, 0], mean) <= TOL and nerr(pr[:, 1], var) <= TOL
+    # size-independent identity: at the training inputs, K alpha = y - noise * alpha, i.e. the posterior mean
+    # reproduces y - noise * alpha (exercises fill, Cholesky, both triangular solves, K*^T fill and the GEMV)
+    at_train = g.predict(X[:, :2048])
+    assert nerr(at_train[:, 0], (y - noise * g.alpha)[:2048]) <= TOL
+    # variances are proper and bounded by the prior variance k(x,x) = 1
+    assert (pr[:, 1] > 0).all() and (pr[:, 1] <= 1.0 + 1e-12).all()
+    assert (at_train[:, 1] > 0).all() and (at_train[:, 1] < noise).all()   # posterior var at a training point < noise
+
+
+def test_full_covariance_diagonal_equals_pointwise_variance():
+    X, y, Xs = _inputs(8192, 8, 384, seed=5)
+    g = GPR(X, y, 0.1, cov_func(sqrexp, l=1.0))
+    pw = g.predict(Xs)
+    mean, cov = g.predict(Xs, pointwise_var=False)
+    assert nerr(np.diag(cov), pw[:, 1]) <= TOL and nerr(mean[:, 0], pw[:, 0]) <= TOL
+    assert nerr(cov, cov.T) <= 1e-12
+    assert np.linalg.eigvalsh((cov + cov.T) / 2).min() > -1e-10          # a covariance matrix

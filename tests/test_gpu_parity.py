@@ -1,0 +1,311 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI by the host mirror of the reference API,
+against (1) the reference's closed-form known answers, (2) the committed golden vectors, (3) the CPU oracle
+on seeded inputs.  Tolerance: normwise 1e-10 in fp64 (BASELINE.json north_star); kernel fills 1e-13."""
+import ctypes as C
+import math
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import TOL, nerr, oracle_params
+import gprc_amd
+from gprc_amd import (GPR, GPC, NotPositiveDefinite, cov_func, covariance_matrix, constant, linear, polynomial, sqrexp,
+                      gammaexp, rationalquadratic)
+from gprc_amd import _native as nat
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+GENERIC = {"constant": constant, "linear": linear, "polynomial": polynomial, "sqrexp": sqrexp, "gammaexp": gammaexp,
+           "rationalquadratic": rationalquadratic}
+
+
+def kfun(kind, params):
+    return cov_func(GENERIC[kind], **params)
+
+
+# ---- the reference's own test file, line by line (tests/testthat/test-gpr.R:5-28) -------------------
+def test_predict_works_reference_known_answers():
+    X1 = np.array([[-1 / 2, 1 / 2]])
+    y1 = np.array([4.0, 4.0])
+    GPRobj1 = GPR.polynomial.new(X1, y1, 1 / 2, 1 / 4, 1)
+    np.testing.assert_allclose(GPRobj1.predict(0).ravel(), [2, 1 / 8], rtol=0, atol=1.5e-8)
+    X2 = np.array([[1.0, 2.0]])
+    y2 = np.array([1.0, 3.0])
+    GPRobj2 = GPR.constant.new(X2, y2, 1, 1)
+    np.testing.assert_allclose(GPRobj2.predict(3).ravel(), [4 / 3, 1 / 3], rtol=0, atol=1.5e-8)
+    X3 = np.array([[100.0, 54.0]])
+    y3 = np.array([5.0, 0.0])
+    GPRobj3 = GPR.constant.new(X3, y3, 1, 1)
+    np.testing.assert_allclose(GPRobj3.predict(math.pi).ravel(), [5 / 3, 1 / 3], rtol=0, atol=1.5e-8)
+    X4 = np.array([[1.0, 2.0]])
+    y4 = np.array([0.0, 1.0])
+    GPRobj4 = GPR.sqrexp.new(X4, y4, 1, 1)
+    cov = 1 - (2 * math.exp(-1) - 2 * math.exp(-3) + 2 * math.exp(-4)) / (4 - math.exp(-1))
+    got = GPRobj4.predict(0).ravel()
+    np.testing.assert_allclose(got, [(2 * math.exp(-2) - math.exp(-1)) / (4 - math.exp(-1)), cov], rtol=0, atol=1.5e-8)
+    # far tighter than the reference's 1.5e-8
+    assert abs(got[0] - (-0.026763669631486305)) < 1e-15 and abs(got[1] - 0.8147594463104431) < 1e-15
+
+
+def test_gpc_works_reference_sign_tests():
+    # tests/testthat/test-gpc.R:5-27 with the constructor's real argument order (X, y, k, epsilon);
+    # kappa(x,y) = exp(-3 (x-y)^2) == sqrexp with l = sqrt(1/6)
+    X = np.round(np.arange(-1, 1.0001, 0.1), 10).reshape(1, -1)
+    y = 2.0 * (X[0] > 0) - 1
+    gc = GPC.new(X, y, cov_func(sqrexp, l=math.sqrt(1 / 6)), 1e-5)
+    assert gc.predict_class(-0.2)[0] < 0.5 < gc.predict_class(0.2)[0]
+    X = np.concatenate([np.round(np.arange(-1, -0.0999, 0.1), 10), np.round(np.arange(0, 1.0001, 0.2), 10)]).reshape(1, -1)
+    y = 2.0 * (X[0] > 0) - 1
+    gc = GPC.new(X, y, cov_func(sqrexp, l=math.sqrt(1 / 6)), 1e-5)
+    assert gc.predict_class(-0.2)[0] < 0.5 < gc.predict_class(0.2)[0]
+    s = np.arange(-1, 1.0001, 0.5)
+    X = np.stack([np.repeat(s, len(s)), np.tile(s, len(s))])
+    y = 2.0 * (X[0] > X[1]) - 1
+    gc = GPC.new(X, y, cov_func(sqrexp, l=1), 1e-5)
+    assert gc.predict_class(np.array([[0.0], [1.0]]))[0] < 0.5 < gc.predict_class(np.array([[-0.3], [-0.9]]))[0]
+
+
+# ---- committed golden vectors ------------------------------------------------------------------------
+def test_golden_closed_forms(golden):
+    for c in golden.of_type("gpr_closed_form"):
+        g = GPR(golden.get(c, "X"), golden.get(c, "y"), c["noise"], kfun(c["kernel"], c["params"]))
+        pr = g.predict(golden.get(c, "Xs"))
+        assert pr.shape == (1, 2)
+        assert abs(pr[0, 0] - golden.get(c, "mean")[0]) < 1e-14 and abs(pr[0, 1] - golden.get(c, "var")[0]) < 1e-14, c["name"]
+
+
+def test_golden_gpr(golden):
+    for c in golden.of_type("gpr"):
+        X, y, Xs = golden.get(c, "X"), golden.get(c, "y"), golden.get(c, "Xs")
+        if c["name"] == "gpr_jitter_duplicates":
+            # K is EXACTLY singular (duplicate points, noise 0): whether the first chol() attempt fails is decided
+            # by the sign of the last rounding error -- LAPACK trips at minor 3, the textbook recurrence at 6, the
+            # right-looking MFMA order may pass.  The reference's own outcome is platform-dependent here, so values
+            # are not compared; the path must still return a finite, documented outcome.
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                g = GPR(X, y, c["noise"], kfun(c["kernel"], c["params"]))
+            assert g.noise in (0.0, 0.01) and np.isfinite(g.alpha).all()
+            continue
+        with warnings.catch_warnings(record=True) as wl:
+            warnings.simplefilter("always")
+            g = GPR(X, y, c["noise"], kfun(c["kernel"], c["params"]))
+        attempts = int(golden.get(c, "attempts")[0])
+        assert g.noise == golden.get(c, "noise")[0], c["name"]
+        assert (len(wl) == 1) == (attempts > 1), c["name"]       # R/GPRclass.R:144 warns iff the noise changed
+        if attempts > 1:
+            assert str(wl[0].message) == f"Noise got changed to {g.noise:.15g} to avoid errors in cholesky decomposition"
+        assert nerr(g.alpha, golden.get(c, "alpha")) <= TOL, c["name"]
+        assert nerr([g.logp], golden.get(c, "logp")) <= TOL, c["name"]
+        assert nerr(np.diag(g.L), golden.get(c, "diagL")) <= TOL, c["name"]
+        if "L" in c["outputs"]:
+            assert nerr(g.L, golden.get(c, "L")) <= TOL, c["name"]
+            assert np.array_equal(np.triu(g.L, 1), np.zeros_like(g.L))       # t(chol(.)) has a zero upper triangle
+            assert nerr(covariance_matrix(X, X, g.k), golden.get(c, "K")) <= 1e-13, c["name"]
+        pr = g.predict(Xs)
+        assert pr.shape == (Xs.shape[1], 2)
+        assert nerr(pr[:, 0], golden.get(c, "mean")) <= TOL and nerr(pr[:, 1], golden.get(c, "var")) <= TOL, c["name"]
+        if "cov" in c["outputs"]:
+            mean, cov = g.predict(Xs, pointwise_var=False)
+            assert mean.shape == (Xs.shape[1], 1) and cov.shape == (Xs.shape[1],) * 2
+            assert nerr(cov, golden.get(c, "cov")) <= TOL and nerr(mean[:, 0], golden.get(c, "mean")) <= TOL, c["name"]
+
+
+def test_golden_not_positive_definite(golden):
+    c = golden.of_type("gpr_notpd")[0]
+    X, y = golden.get(c, "X"), golden.get(c, "y")
+    ctx = nat.default_context()
+    _, pp, npar = nat.params_array(oracle_params(c["kernel"], c["params"]))
+    model = C.c_void_p()
+    Xf = np.asfortranarray(X)
+    rc = nat.lib().gprc_gpr_fit(ctx.handle, nat.POLYNOMIAL, pp, npar, Xf.ctypes.data, 1, X.shape[1], y.ctypes.data, 0.0, C.byref(model))
+    assert rc == int(golden.get(c, "info_first")[0]) == 2          # LAPACK info through the C ABI
+    assert "leading minor of order 2" in nat.last_error()
+    with pytest.raises(NotPositiveDefinite) as ei:
+        nat.check(rc)
+    assert ei.value.info == 2
+    with pytest.raises(ArithmeticError, match="Inputs lead to non positive definite covariance matrix"):
+        GPR(X, y, 0.0, kfun(c["kernel"], c["params"]))               # R/GPRclass.R:149
+
+
+def test_golden_gpc(golden):
+    for c in golden.of_type("gpc"):
+        X, y, Xs = golden.get(c, "X"), golden.get(c, "y"), golden.get(c, "Xs")
+        gc = GPC(X, y, kfun(c["kernel"], c["params"]), c["epsilon"])
+        assert gc.iterations == int(golden.get(c, "iters")[0]), c["name"]
+        assert nerr(gc.f_hat, golden.get(c, "f_hat")) <= 1e-9, c["name"]
+        assert nerr([gc.logq], golden.get(c, "logq")) <= 1e-9, c["name"]
+        assert nerr(np.diag(gc.L), golden.get(c, "diagL")) <= 1e-9, c["name"]
+        fs, vf = gc.predict_latent(Xs)
+        assert nerr(fs, golden.get(c, "fs_bar")) <= 1e-9 and nerr(vf, golden.get(c, "Vfs")) <= 1e-9, c["name"]
+        assert nerr(gc.predict_class(Xs), golden.get(c, "prob")) <= 1e-7, c["name"]   # QUADPACK on both sides
+
+
+# ---- against the oracle on seeded inputs --------------------------------------------------------------
+KERNELS = [("constant", dict(c=1.7)), ("linear", dict(sigma=0.7)), ("polynomial", dict(sigma=0.5, p=3.0)),
+           ("polynomial", dict(sigma=0.25, p=2.0)), ("sqrexp", dict(l=1.3)), ("gammaexp", dict(l=0.9, gamma=1.5)),
+           ("gammaexp", dict(l=0.9, gamma=2.0)), ("rationalquadratic", dict(l=1.1, alpha=1.5))]
+
+
+@pytest.mark.parametrize("d,nA,nB", [(1, 1, 1), (1, 5, 3), (2, 130, 67), (8, 257, 300), (20, 64, 129), (37, 300, 10)])
+def test_covariance_matrix_all_kernels(d, nA, nB):
+    rng = np.random.default_rng(100 + d)
+    A, B = rng.uniform(-1, 1, (d, nA)), rng.uniform(-1, 1, (d, nB))
+    for kind, par in KERNELS + [("linear", dict(sigma=list(rng.uniform(0.2, 1.5, d))))]:
+        k = kfun(kind, par)
+        ref = orc.kernel_matrix(orc.KERNEL_IDS[kind], oracle_params(kind, par), A, B)
+        got = covariance_matrix(A, B, k)
+        assert got.shape == (nA, nB) and got.flags.f_contiguous
+        assert nerr(got, ref) <= 1e-13, (kind, par)
+        m = min(nA, nB)
+        assert nerr(k(A[:, :m], B[:, :m]), np.diag(ref)[:m]) <= 1e-13           # the closure contract
+    assert covariance_matrix(A, B[:, :0], kfun("sqrexp", dict(l=1.0))).shape == (nA, 0)
+    Ksym = covariance_matrix(A, A, kfun("gammaexp", dict(l=0.9, gamma=1.5)))
+    assert np.array_equal(Ksym, Ksym.T)                                           # bitwise symmetric, like the reference
+
+
+def test_kernel_scalar_methods():
+    # the .numeric methods (R/GPRclass.R:383-403): two vectors -> one number
+    x, y = np.array([0.3, -0.2, 0.9]), np.array([0.1, 0.4, -0.5])
+    assert abs(sqrexp(x, y, l=0.7) - math.exp(-((x - y) ** 2).sum() / (2 * 0.49))) < 1e-15
+    assert abs(polynomial(x, y, 0.5, 3) - (x @ y + 0.5) ** 3) < 1e-15
+    assert abs(linear(x, y, sigma=[1.0, 2.0, 3.0]) - (np.array([1.0, 2.0, 3.0]) * x * y).sum()) < 1e-15
+    assert constant(x, y, c=4.0) == 4.0
+
+
+@pytest.mark.parametrize("n,d,ns", [(1, 1, 4), (127, 3, 129), (513, 2, 50), (1500, 8, 333)])
+def test_gpr_against_oracle(n, d, ns):
+    rng = np.random.default_rng(n)
+    X = rng.uniform(-1, 1, (d, n))
+    y = 0.1 * (X ** 3).sum(0) + rng.normal(0, 0.1, n)
+    Xs = rng.uniform(-1, 1, (d, ns))
+    kinds = KERNELS if n <= 600 else [("sqrexp", dict(l=1.0)), ("rationalquadratic", dict(l=1.0, alpha=1.5))]
+    for kind, par in kinds:
+        noise = 0.1
+        f = orc.gpr_fit(orc.KERNEL_IDS[kind], oracle_params(kind, par), X, y, noise)
+        g = GPR(X, y, noise, kfun(kind, par))
+        assert g.noise == f["noise"]
+        assert nerr(g.L, f["L"]) <= TOL and nerr(g.alpha, f["alpha"]) <= TOL, (kind, n)
+        assert abs(g.logp - f["logp"]) <= TOL * abs(f["logp"])
+        mr, vr = orc.gpr_predict(orc.KERNEL_IDS[kind], oracle_params(kind, par), X, f["L"], f["alpha"], Xs)
+        pr = g.predict(Xs)
+        assert nerr(pr[:, 0], mr) <= TOL and nerr(pr[:, 1], vr) <= TOL, (kind, n)
+        if ns <= 130:
+            mean, cov = g.predict(Xs, pointwise_var=False)
+            _, cr = orc.gpr_predict(orc.KERNEL_IDS[kind], oracle_params(kind, par), X, f["L"], f["alpha"], Xs, pointwise=False)
+            assert nerr(cov, cr) <= TOL and nerr(np.diag(cov), pr[:, 1]) <= TOL
+
+
+def test_predict_input_forms_and_edges():
+    rng = np.random.default_rng(1)
+    X = rng.uniform(-1, 1, (2, 40))
+    y = rng.normal(size=40)
+    g = GPR(X, y, 0.1, cov_func(sqrexp, l=1.0))
+    Xs = rng.uniform(-1, 1, (2, 6))
+    a = g.predict(Xs)
+    b = g.predict(Xs.reshape(-1, order="F"))                     # bare vector -> d x len/d (R/GPRclass.R:157-159)
+    assert np.array_equal(a, b)
+    assert g.predict(np.zeros((2, 0))).shape == (0, 2)           # empty X_star
+    with pytest.raises(ValueError):
+        g.predict(np.zeros(3))                                   # length %% nrow(X) != 0
+    for name in ("X", "k", "y", "noise", "L", "alpha", "logp"):
+        with pytest.raises(AttributeError, match="read only"):
+            setattr(g, name, 0)
+    assert np.array_equal(g.X, X) and np.array_equal(g.y, y)
+    g1 = GPR(np.array([0.1, 0.5, 0.9]), np.array([1.0, 2.0, 3.0]), 0.5, cov_func(sqrexp, l=1.0))  # vector X -> 1 x n
+    assert g1.X.shape == (1, 3) and g1.predict(0.3).shape == (1, 2)
+
+
+def test_chunked_predict_is_bitwise_chunk_invariant(monkeypatch):
+    rng = np.random.default_rng(2)
+    d, n, ns = 4, 700, 900
+    X = rng.uniform(-1, 1, (d, n))
+    y = rng.normal(size=n)
+    Xs = rng.uniform(-1, 1, (d, ns))
+    g = GPR(X, y, 0.1, cov_func(sqrexp, l=1.0))
+    whole = g.predict(Xs)
+    monkeypatch.setenv("GPRC_CHUNK_BYTES", str(256 * 1024 * 8))  # 256 rows per chunk at n_pad = 1024
+    ctx2 = nat.Context(0)
+    g2 = GPR(X, y, 0.1, cov_func(sqrexp, l=1.0), ctx=ctx2)
+    parts = g2.predict(Xs)
+    assert np.array_equal(whole, parts)
+    g2.close()
+    ctx2.close()
+
+
+def test_device_pointers_are_used_in_place():
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(3)
+    d, n, ns = 5, 300, 77
+    X = np.asfortranarray(rng.uniform(-1, 1, (d, n)))
+    y = rng.normal(size=n)
+    Xs = np.asfortranarray(rng.uniform(-1, 1, (d, ns)))
+    host = GPR(X, y, 0.1, cov_func(sqrexp, l=1.0)).predict(Xs)
+    dev = torch.device("cuda:0")
+    Xd, yd = torch.from_numpy(X.T.copy()).to(dev), torch.from_numpy(y).to(dev)
+    Xsd = torch.from_numpy(Xs.T.copy()).to(dev)
+    mean, var = torch.empty(ns, dtype=torch.float64, device=dev), torch.empty(ns, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    ctx = nat.default_context()
+    _, pp, npar = nat.params_array([1.0])
+    model = C.c_void_p()
+    nat.check(nat.lib().gprc_gpr_fit(ctx.handle, nat.SQREXP, pp, npar, Xd.data_ptr(), d, n, yd.data_ptr(), 0.1, C.byref(model)))
+    nat.check(nat.lib().gprc_gpr_predict(model, Xsd.data_ptr(), ns, 1, mean.data_ptr(), var.data_ptr()))
+    nat.lib().gprc_model_free(model)
+    assert np.array_equal(mean.cpu().numpy(), host[:, 0]) and np.array_equal(var.cpu().numpy(), host[:, 1])
+
+
+def test_gpc_against_oracle_random():
+    rng = np.random.default_rng(4)
+    X = rng.uniform(-1, 1, (3, 600))                              # two panels
+    y = np.sign(X.sum(0) + 0.2 * rng.normal(size=600))
+    y[y == 0] = 1.0
+    Xs = rng.uniform(-1, 1, (3, 41))
+    # the reference's stop rule (R/GPCclass.R:90-91) fires on this problem: the objective improves by > 10
+    # after iteration 1.  Parity includes that error ...
+    with pytest.raises(ArithmeticError, match="Apparently does not converge."):
+        orc.gpc_fit(orc.SQREXP, [1.0], X, y, 1e-5)
+    with pytest.raises(ArithmeticError, match="Apparently does not converge."):
+        GPC(X, y, cov_func(sqrexp, l=1.0), 1e-5)
+    # ... and with the rule switched off on both sides the numbers agree
+    oc = orc.gpc_fit(orc.SQREXP, [1.0], X, y, 1e-5, divergence_stop=False)
+    gc = GPC(X, y, cov_func(sqrexp, l=1.0), 1e-5, reference_stop=False)
+    assert gc.iterations == oc["iters"]
+    assert nerr(gc.f_hat, oc["f_hat"]) <= 1e-9 and abs(gc.logq - oc["logq"]) <= 1e-9 * abs(oc["logq"])
+    assert nerr(gc.L, oc["L"]) <= 1e-9
+    fs, vf = gc.predict_latent(Xs)
+    ofs, ovf = orc.gpc_predict_latent(orc.SQREXP, [1.0], X, y, oc["f_hat"], oc["L"], Xs)
+    assert nerr(fs, ofs) <= 1e-9 and nerr(vf, ovf) <= 1e-9
+    for name in ("X", "k", "y", "f_hat", "L", "logq"):
+        with pytest.raises(AttributeError, match="read only"):
+            setattr(gc, name, 0)
+
+
+def test_distributed_driver_single_rank_matches_host_path():
+    """The bench/multi-GPU driver (world 1, with and without look-ahead) gives the host path's numbers."""
+    pytest.importorskip("torch")
+    from gprc_amd.distributed import DistributedGPR, HipOps, SingleComm
+    rng = np.random.default_rng(5)
+    d, n, ns = 8, 1700, 260
+    X = rng.uniform(-1, 1, (n, d))
+    y = rng.normal(size=n)
+    Xs = rng.uniform(-1, 1, (ns, d))
+    g = GPR(X.T, y, 0.1, cov_func(sqrexp, l=1.0))
+    ref = g.predict(Xs.T)
+    for look in (True, False):
+        ops = HipOps(0, nat.SQREXP, [1.0], d, n, 0.1)
+        eng = DistributedGPR(ops, SingleComm(), lookahead=look)
+        ypad = np.zeros(ops.geom.n_pad)
+        ypad[:n] = y
+        Xd, yd, Xsd = ops.from_host(X), ops.from_host(ypad), ops.from_host(Xs)
+        mean, var = ops.zeros(ns), ops.zeros(ns)
+        for _ in range(2):                                        # twice: buffers are reused across steps
+            assert eng.fit(Xd, yd) == 0
+            eng.predict_local(Xd, yd, Xsd, ns, mean, var)
+        assert np.array_equal(ops.to_host(eng.alpha)[:n], g.alpha)
+        assert np.array_equal(ops.to_host(mean), ref[:, 0]) and np.array_equal(ops.to_host(var), ref[:, 1])
+        assert abs(float(ops.to_host(eng.scal)[0]) - g.logp) <= 1e-12 * abs(g.logp)
+        ops.close()

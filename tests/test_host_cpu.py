@@ -1,0 +1,132 @@
+"""Host-side logic that needs no GPU: cov_func argument matching and tagging, argument validation in the
+reference's stopifnot() order, read-only bindings, packed-layout index arithmetic, and the loud failure of
+the compute path when no MI355X is present (no CPU fallback)."""
+import numpy as np
+import pytest
+
+import gprc_amd
+from gprc_amd import (GPR, GPC, GprcError, cov_func, covariance_matrix, constant, linear, polynomial, sqrexp, gammaexp,
+                      rationalquadratic)
+from gprc_amd import _native as nat
+from gprc_amd.covfunc import as_points
+from gprc_amd.gpr import _ReadOnly, _r_num
+from conftest import gpu_available
+
+
+def test_cov_func_tags_and_argument_matching():
+    k = cov_func(sqrexp, l=0.1)                                  # man/cov_func.Rd example
+    assert k.gprc_kernel[0] == nat.SQREXP and k.gprc_kernel[1].tolist() == [0.1]
+    k = cov_func(rationalquadratic, l=1, alpha=0.5)
+    assert k.gprc_kernel[0] == nat.RATQUAD and k.gprc_kernel[1].tolist() == [1.0, 0.5]
+    # R argument matching: named first, then positional in signature order (x, y, l, gamma)
+    assert cov_func(gammaexp, 0.9, 1.5).params.tolist() == [0.9, 1.5]
+    assert cov_func(gammaexp, gamma=1.5, l=0.9).params.tolist() == [0.9, 1.5]
+    assert cov_func(gammaexp, 0.9, gamma=1.5).params.tolist() == [0.9, 1.5]
+    assert cov_func(polynomial, sigma=0.25, p=1).params.tolist() == [0.25, 1.0]
+    assert cov_func(linear, sigma=[0.1, 0.2, 0.3]).params.tolist() == [0.1, 0.2, 0.3]
+    assert cov_func(constant, 2).params.tolist() == [2.0]
+    with pytest.raises(TypeError):
+        cov_func(sqrexp)                                         # argument "l" is missing
+    with pytest.raises(TypeError):
+        cov_func(sqrexp, 1.0, 2.0)
+    with pytest.raises(TypeError):
+        cov_func(sqrexp, gamma=2.0)                              # unused argument
+    with pytest.raises(TypeError):
+        cov_func(lambda x, y: np.exp(-3 * (x - y) ** 2))         # arbitrary closures stay on the R path
+
+
+def test_untagged_closures_are_rejected_loudly():
+    kappa = lambda x, y: np.exp(-3 * (x - y) ** 2)               # noqa: E731  (tests/testthat/test-gpc.R:7)
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        covariance_matrix(np.zeros((1, 3)), np.zeros((1, 3)), kappa)
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        GPR(np.zeros((1, 3)), np.zeros(3), 0.1, kappa)
+    with pytest.raises(TypeError):
+        GPC(np.zeros((1, 3)), np.array([1.0, -1.0, 1.0]), 1e-5, kappa)   # the stale argument order of test-gpc.R:8
+
+
+def test_argument_validation_mirrors_stopifnot():
+    k = cov_func(sqrexp, l=1.0)
+    X = np.zeros((2, 4))
+    y = np.zeros(4)
+    with pytest.raises(TypeError):
+        GPR(np.array(["a", "b"]), y, 0.1, k)                     # is.numeric(X)
+    with pytest.raises(TypeError):
+        GPR(X, np.zeros((4, 1)), 0.1, k)                         # is.vector(y)
+    with pytest.raises(ValueError):
+        GPR(X, y, -1.0, k)                                       # noise >= 0
+    with pytest.raises(ValueError):
+        GPR(X, y, [0.1, 0.2], k)                                 # length(noise) == 1
+    with pytest.raises(ValueError):
+        GPR(X, np.zeros(3), 0.1, k)                              # length(y) == ncol(X)
+    with pytest.raises(TypeError):
+        GPR(X, y, 0.1, 3.0)                                      # is.function(k)
+    with pytest.raises(NotImplementedError):
+        GPR(X, y, 0.1)                                           # default k = fit(...)$func: SURVEY 8f "next"
+    with pytest.raises(TypeError):
+        GPC(X, y, k, epsilon=0.0)                                # epsilon > 0
+    with pytest.raises(ValueError):
+        gprc_amd.GPR_linear(X, y, 0.1, sigma=[1.0, 2.0, 3.0])    # length(sigma) == nrow(X)
+    with pytest.raises(ValueError):
+        gprc_amd.GPR_sqrexp(X, y, 0.1, l=[1.0, 2.0])             # length(l) == 1
+    with pytest.raises(ValueError):
+        gprc_amd.GPR_constant(X, y, 0.1, c=-1.0)                 # c > 0
+    assert GPR.sqrexp is gprc_amd.GPR_sqrexp and GPR.rationalquadratic is gprc_amd.GPR_rationalquadratic
+
+
+def test_vector_inputs_become_matrices():
+    assert as_points([1.0, 2.0, 3.0]).shape == (1, 3)                        # R/GPRclass.R:132
+    Xs = as_points(np.arange(6.0), d=2, what="X_star")                       # R/GPRclass.R:157-159: column by column
+    assert Xs.shape == (2, 3) and Xs[:, 1].tolist() == [2.0, 3.0]
+    with pytest.raises(ValueError):
+        as_points(np.arange(5.0), d=2, what="X_star")
+
+
+def test_read_only_bindings():
+    class T:
+        X = _ReadOnly("X", lambda s: 42)
+    t = T()
+    assert t.X == 42
+    with pytest.raises(AttributeError, match=r"`\$X` is read only"):        # R/GPRclass.R:234
+        t.X = 1
+    for name in ("X", "k", "y", "noise", "L", "alpha", "logp"):
+        assert isinstance(GPR.__dict__[name], _ReadOnly)
+    for name in ("X", "k", "y", "f_hat", "L", "logq"):
+        assert isinstance(GPC.__dict__[name], _ReadOnly)
+
+
+def test_r_number_formatting():
+    assert _r_num(0.01) == "0.01" and _r_num(0.060000000000000005) == "0.06" and _r_num(1.0) == "1"
+
+
+def test_packed_layout_arithmetic():
+    L = nat.lib()
+    NB = L.gprc_panel_width()
+    assert NB % 128 == 0
+    for n in (1, 2, 127, 512, 513, 8192, 65536):
+        n_pad = L.gprc_pad(n)
+        assert n_pad % NB == 0 and n <= n_pad < n + NB
+        P = L.gprc_panel_count(n_pad)
+        off = 0
+        for p in range(P):
+            assert L.gprc_panel_offset(n_pad, p) == off
+            assert L.gprc_panel_elems(n_pad, p) == (n_pad - p * NB) * NB
+            off += (n_pad - p * NB) * NB
+        assert L.gprc_packed_size(n_pad) == off
+        assert L.gprc_winv_size(n_pad) == n_pad * 128
+    # the factor at n = 65536 takes ~half of a dense matrix
+    n_pad = L.gprc_pad(65536)
+    assert L.gprc_packed_size(n_pad) * 8 < 0.51 * 8 * 65536 ** 2
+
+
+@pytest.mark.skipif(gpu_available(), reason="checks the no-GPU failure mode")
+def test_compute_fails_loudly_without_gpu():
+    assert gprc_amd.device_count() == 0
+    k = cov_func(sqrexp, l=1.0)
+    with pytest.raises(GprcError) as ei:
+        GPR(np.zeros((1, 3)), np.zeros(3), 0.1, k)
+    assert ei.value.status == nat.ERR_NO_DEVICE and "no CPU fallback" in ei.value.message
+    with pytest.raises(GprcError):
+        covariance_matrix(np.zeros((1, 3)), np.zeros((1, 3)), k)
+    with pytest.raises(GprcError):
+        k(np.zeros((1, 3)), np.zeros((1, 3)))

@@ -135,7 +135,7 @@ def main():
         Xsd = torch.from_numpy(np.ascontiguousarray(Xs.T)).to(dev)
         vt = torch.zeros(m_pad * n_pad, dtype=torch.float64, device=dev)
         torch.cuda.synchronize()
-        nat.check(L.gprc_dev_fill_cross(ctx.handle, orc.SQREXP, pp, npar, Xsd.data_ptr(), d, m, m_pad, Xd.data_ptr(), n, n_pad, vt.data_ptr()))
+        nat.check(L.gprc_dev_fill_cross(ctx.handle, orc.SQREXP, pp, npar, Xsd.data_ptr(), d, m, m_pad, Xd.data_ptr(), n, n_pad, vt.data_ptr(), m_pad))
         ctx.synchronize()
         Kst = np.zeros((m_pad, n_pad))
         Kst[:m, :n] = orc.kernel_matrix(orc.SQREXP, par, Xs, X)
@@ -147,7 +147,7 @@ def main():
         nat.check(L.gprc_dev_row_reduce(ctx.handle, vt.data_ptr(), m_pad, m_pad, n_pad, w.data_ptr(), out.data_ptr(), rwork.data_ptr()))
         ctx.synchronize()
         report(f"row_reduce dot n={n}", out.cpu().numpy(), Kst @ w.cpu().numpy(), 1e-12)
-        nat.check(L.gprc_dev_solve_rows(ctx.handle, packed.data_ptr(), winv.data_ptr(), n_pad, vt.data_ptr(), m_pad))
+        nat.check(L.gprc_dev_solve_rows(ctx.handle, packed.data_ptr(), winv.data_ptr(), n_pad, vt.data_ptr(), m_pad, m_pad))
         ctx.synchronize()
         Vref = sl.solve_triangular(Lref, Kst.T, lower=True).T
         report(f"solve_rows n={n}", vt.cpu().numpy().reshape(n_pad, m_pad).T, Vref, 1e-11)
