@@ -1,0 +1,80 @@
+# native.R -- R-side dispatch onto libgprc_native.so for the reference package `gprc`.
+#
+# NOT EXERCISED IN THIS REPOSITORY (no R toolchain in the build image).  It shows the few lines a
+# maintainer adds next to R/GPRclass.R / R/GPCclass.R; everything else in the package stays as it is.
+# Dispatch rule: a covariance function built by cov_func() from one of the six package kernels carries
+# attr(k, "gprc_kernel") = list(id, params); with that tag and a visible MI355X the hot path runs
+# natively, otherwise the original R expressions run unchanged (arbitrary user closures, no GPU).
+
+.gprc_kernel_ids <- c(constant = 0L, linear = 1L, polynomial = 2L, sqrexp = 3L, gammaexp = 4L, rationalquadratic = 5L)
+# parameter order of the native ABI (include/gprc_native.h)
+.gprc_param_order <- list(constant = "c", linear = "sigma", polynomial = c("sigma", "p"), sqrexp = "l",
+                          gammaexp = c("l", "gamma"), rationalquadratic = c("l", "alpha"))
+
+gprc_native_available <- function() {
+  isTRUE(getOption("gprc.backend", "auto") != "R") && .Call(gprc_R_device_count) > 0L
+}
+
+# replaces cov_func (R/GPRclass.R:424-427): same closure, plus the tag
+cov_func <- function(func, ...) {
+  force(func)
+  args <- list(...)
+  k <- function(x, y) func(x, y, ...)
+  name <- names(Filter(function(f) identical(f, func), mget(names(.gprc_kernel_ids), envir = environment(cov_func))))
+  if (length(name) == 1L) {
+    ord <- .gprc_param_order[[name]]
+    if (is.null(names(args))) names(args) <- ord[seq_along(args)]
+    if (all(ord %in% names(args)))
+      attr(k, "gprc_kernel") <- list(id = .gprc_kernel_ids[[name]], params = as.double(unlist(args[ord])))
+  }
+  k
+}
+
+# replaces covariance_matrix (R/GPRclass.R:355-357)
+covariance_matrix <- function(A, B, covariance_function) {
+  tag <- attr(covariance_function, "gprc_kernel")
+  if (!is.null(tag) && gprc_native_available()) {
+    storage.mode(A) <- "double"; storage.mode(B) <- "double"
+    return(.Call(gprc_R_kernel_matrix, tag$id, tag$params, A, B))
+  }
+  outer(1:ncol(A), 1:ncol(B), function(i, j) covariance_function(A[, i, drop = F], B[, j, drop = F]))
+}
+
+# body of GPR$initialize after the input checks (R/GPRclass.R:134-153), native branch
+.gpr_initialize_native <- function(private, X, y, noise, k) {
+  tag <- attr(k, "gprc_kernel")
+  storage.mode(X) <- "double"
+  res <- .Call(gprc_R_gpr_fit, tag$id, tag$params, X, as.double(y), as.double(noise))
+  if (res[[3]] > 1L) warning(sprintf("Noise got changed to %s to avoid errors in cholesky decomposition", res[[2]]))
+  private$.handle <- res[[1]]
+  private$.noise <- res[[2]]
+  private$.alpha <- res[[4]]
+  private$.logp <- matrix(res[[5]], 1, 1)
+  private$.L <- NULL            # fetched by the `L` active binding on first read: .Call(gprc_R_model_L, handle)
+}
+
+# body of GPR$predict (R/GPRclass.R:160-169), native branch
+.gpr_predict_native <- function(private, X_star, pointwise_var) {
+  storage.mode(X_star) <- "double"
+  .Call(gprc_R_gpr_predict, private$.handle, X_star, isTRUE(pointwise_var))
+}
+
+# body of GPC$initialize (R/GPCclass.R:73-103), native branch
+.gpc_initialize_native <- function(private, X, y, k, epsilon) {
+  tag <- attr(k, "gprc_kernel")
+  storage.mode(X) <- "double"
+  res <- .Call(gprc_R_gpc_fit, tag$id, tag$params, X, as.double(y), as.double(epsilon))
+  message(sprintf("Convergence after %s iterations", res[[4]]))
+  private$.handle <- res[[1]]
+  private$.f_hat <- res[[2]]
+  private$.logq <- res[[3]]
+}
+
+# GPC$predict_class (R/GPCclass.R:108-118), native branch: fs_bar / Vfs on the GPU, integrate() as before
+.gpc_predict_class_native <- function(private, X_star) {
+  if (!is.matrix(X_star)) dim(X_star) <- c(1, length(X_star))
+  storage.mode(X_star) <- "double"
+  lat <- .Call(gprc_R_gpc_predict_latent, private$.handle, X_star)
+  sapply(seq_len(nrow(lat)), function(i) integrate(function(z)
+    private$.sigmoid(z) * dnorm(z, mean = lat[i, 1], sd = lat[i, 2]), -Inf, Inf)$value)
+}

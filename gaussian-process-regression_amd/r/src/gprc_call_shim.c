@@ -1,0 +1,170 @@
+/*
+ * gprc_call_shim.c -- the `.Call` layer between the R package `gprc` and libgprc_native.so.
+ *
+ * NOT COMPILED IN THIS REPOSITORY'S BUILD: the build image has no R toolchain (no Rinternals.h).  It is
+ * the file a maintainer drops into the reference package's src/ (with `useDynLib(gprc, .registration =
+ * TRUE)` in NAMESPACE and PKG_LIBS = -lgprc_native).  It only marshals: every pointer handed to the C ABI
+ * is REAL(x) of a caller-owned SEXP, borrowed for the call; results are allocated here and filled by the
+ * library; model handles live behind external pointers with a finalizer.  Status codes are turned into R
+ * conditions AFTER all temporaries are released (Rf_error longjmps).
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+
+#include "gprc_native.h"
+
+static gprc_ctx* g_ctx = NULL;
+
+static gprc_ctx* ctx(void) {
+  if (!g_ctx && gprc_ctx_create(0, NULL, &g_ctx) != 0) Rf_error("gprc: %s", gprc_last_error());
+  return g_ctx;
+}
+
+static void model_finalizer(SEXP ptr) {
+  gprc_model* m = (gprc_model*)R_ExternalPtrAddr(ptr);
+  if (m) { gprc_model_free(m); R_ClearExternalPtr(ptr); }
+}
+
+static SEXP wrap_model(gprc_model* m) {
+  SEXP ptr = PROTECT(R_MakeExternalPtr(m, Rf_install("gprc_model"), R_NilValue));
+  R_RegisterCFinalizerEx(ptr, model_finalizer, TRUE);
+  UNPROTECT(1);
+  return ptr;
+}
+
+static gprc_model* model_of(SEXP ptr) {
+  gprc_model* m = (gprc_model*)R_ExternalPtrAddr(ptr);
+  if (!m) Rf_error("gprc: model handle is NULL (object restored from a saved workspace?)");
+  return m;
+}
+
+/* covariance_matrix(A, B, k) for a tagged kernel  --  R/GPRclass.R:355-357 */
+SEXP gprc_R_kernel_matrix(SEXP kernel, SEXP params, SEXP A, SEXP B) {
+  const int64_t d = Rf_nrows(A), nA = Rf_ncols(A), nB = Rf_ncols(B);
+  SEXP out = PROTECT(Rf_allocMatrix(REALSXP, (int)nA, (int)nB));
+  int rc = gprc_kernel_matrix(ctx(), Rf_asInteger(kernel), REAL(params), LENGTH(params), REAL(A), d, nA, REAL(B), nB, REAL(out), nA);
+  UNPROTECT(1);
+  if (rc != 0) Rf_error("gprc: %s", gprc_last_error());
+  return out;
+}
+
+/* GPR$initialize  --  R/GPRclass.R:138-153.  Returns list(handle, noise, attempts, alpha, logp). */
+SEXP gprc_R_gpr_fit(SEXP kernel, SEXP params, SEXP X, SEXP y, SEXP noise) {
+  const int64_t d = Rf_nrows(X), n = Rf_ncols(X);
+  gprc_model* m = NULL;
+  double noise_used = 0.0;
+  int attempts = 0;
+  int rc = gprc_gpr_fit_retry(ctx(), Rf_asInteger(kernel), REAL(params), LENGTH(params), REAL(X), d, n, REAL(y), Rf_asReal(noise), &m,
+                              &noise_used, &attempts);
+  if (rc == GPRC_ERR_NOT_PD)
+    Rf_error("Inputs lead to non positive definite covariance matrix. Try using a larger noise or a smaller lengthscale.");
+  if (rc != 0) Rf_error("gprc: %s", gprc_last_error());
+  SEXP res = PROTECT(Rf_allocVector(VECSXP, 5));
+  SET_VECTOR_ELT(res, 0, wrap_model(m));
+  SET_VECTOR_ELT(res, 1, Rf_ScalarReal(noise_used));
+  SET_VECTOR_ELT(res, 2, Rf_ScalarInteger(attempts));
+  SEXP alpha = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t)n));
+  double logp = 0.0;
+  gprc_gpr_get_alpha(m, REAL(alpha));
+  gprc_gpr_get_logp(m, &logp);
+  SET_VECTOR_ELT(res, 3, alpha);
+  SET_VECTOR_ELT(res, 4, Rf_ScalarReal(logp));
+  UNPROTECT(2);
+  return res;
+}
+
+/* GPR$predict  --  R/GPRclass.R:155-170.  pointwise: n* x 2 matrix; else list(mean n* x 1, cov n* x n*). */
+SEXP gprc_R_gpr_predict(SEXP handle, SEXP X_star, SEXP pointwise) {
+  gprc_model* m = model_of(handle);
+  const int64_t ns = Rf_ncols(X_star);
+  const int pw = Rf_asLogical(pointwise);
+  SEXP res;
+  int rc;
+  if (pw) {
+    res = PROTECT(Rf_allocMatrix(REALSXP, (int)ns, 2));
+    rc = gprc_gpr_predict(m, REAL(X_star), ns, 1, REAL(res), REAL(res) + ns);
+    UNPROTECT(1);
+  } else {
+    res = PROTECT(Rf_allocVector(VECSXP, 2));
+    SEXP mean = PROTECT(Rf_allocMatrix(REALSXP, (int)ns, 1));
+    SEXP cov = PROTECT(Rf_allocMatrix(REALSXP, (int)ns, (int)ns));
+    rc = gprc_gpr_predict(m, REAL(X_star), ns, 0, REAL(mean), REAL(cov));
+    SET_VECTOR_ELT(res, 0, mean);
+    SET_VECTOR_ELT(res, 1, cov);
+    UNPROTECT(3);
+  }
+  if (rc != 0) Rf_error("gprc: %s", gprc_last_error());
+  return res;
+}
+
+/* `$L` active binding: materialised lazily (n x n doubles over PCIe) */
+SEXP gprc_R_model_L(SEXP handle) {
+  gprc_model* m = model_of(handle);
+  int64_t n = 0, d = 0;
+  gprc_model_dims(m, &n, &d);
+  SEXP L = PROTECT(Rf_allocMatrix(REALSXP, (int)n, (int)n));
+  int rc = gprc_model_get_L(m, REAL(L), n);
+  UNPROTECT(1);
+  if (rc != 0) Rf_error("gprc: %s", gprc_last_error());
+  return L;
+}
+
+/* GPC$initialize  --  R/GPCclass.R:66-107.  Returns list(handle, f_hat, logq, iterations). */
+SEXP gprc_R_gpc_fit(SEXP kernel, SEXP params, SEXP X, SEXP y, SEXP epsilon) {
+  const int64_t d = Rf_nrows(X), n = Rf_ncols(X);
+  gprc_model* m = NULL;
+  int iters = 0;
+  int rc = gprc_gpc_fit(ctx(), Rf_asInteger(kernel), REAL(params), LENGTH(params), REAL(X), d, n, REAL(y), Rf_asReal(epsilon), 0,
+                        GPRC_GPC_REFERENCE_STOP, &m, &iters);
+  if (rc == GPRC_ERR_DIVERGED) Rf_error("Apparently does not converge.");
+  if (rc != 0) Rf_error("gprc: %s", gprc_last_error());
+  SEXP res = PROTECT(Rf_allocVector(VECSXP, 4));
+  SET_VECTOR_ELT(res, 0, wrap_model(m));
+  SEXP f = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t)n));
+  double logq = 0.0;
+  gprc_gpc_get_f_hat(m, REAL(f));
+  gprc_gpc_get_logq(m, &logq);
+  SET_VECTOR_ELT(res, 1, f);
+  SET_VECTOR_ELT(res, 2, Rf_ScalarReal(logq));
+  SET_VECTOR_ELT(res, 3, Rf_ScalarInteger(iters));
+  UNPROTECT(2);
+  return res;
+}
+
+/* fs_bar, Vfs of GPC$predict_class  --  R/GPCclass.R:109-115; the integrate() loop stays in R */
+SEXP gprc_R_gpc_predict_latent(SEXP handle, SEXP X_star) {
+  gprc_model* m = model_of(handle);
+  const int64_t ns = Rf_ncols(X_star);
+  SEXP res = PROTECT(Rf_allocMatrix(REALSXP, (int)ns, 2));
+  int rc = gprc_gpc_predict_latent(m, REAL(X_star), ns, REAL(res), REAL(res) + ns);
+  UNPROTECT(1);
+  if (rc != 0) Rf_error("gprc: %s", gprc_last_error());
+  return res;
+}
+
+SEXP gprc_R_device_count(void) {
+  int c = 0;
+  gprc_device_count(&c);
+  return Rf_ScalarInteger(c);
+}
+
+static const R_CallMethodDef call_methods[] = {
+    {"gprc_R_kernel_matrix", (DL_FUNC)&gprc_R_kernel_matrix, 4},
+    {"gprc_R_gpr_fit", (DL_FUNC)&gprc_R_gpr_fit, 5},
+    {"gprc_R_gpr_predict", (DL_FUNC)&gprc_R_gpr_predict, 3},
+    {"gprc_R_model_L", (DL_FUNC)&gprc_R_model_L, 1},
+    {"gprc_R_gpc_fit", (DL_FUNC)&gprc_R_gpc_fit, 5},
+    {"gprc_R_gpc_predict_latent", (DL_FUNC)&gprc_R_gpc_predict_latent, 2},
+    {"gprc_R_device_count", (DL_FUNC)&gprc_R_device_count, 0},
+    {NULL, NULL, 0}};
+
+void R_init_gprc(DllInfo* dll) {
+  R_registerRoutines(dll, NULL, call_methods, NULL, NULL);
+  R_useDynamicSymbols(dll, FALSE);
+}
+
+void R_unload_gprc(DllInfo* dll) {
+  (void)dll;
+  if (g_ctx) { gprc_ctx_destroy(g_ctx); g_ctx = NULL; }
+}
