@@ -20,60 +20,79 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// Diagonal block: Cholesky + inverse in one LDS-resident sweep.
-//
-// S is a 128 x 129 column-major LDS array.  At step j, column j of S holds, by row c:
-//   c > j : L[c][j]                 (the Cholesky column, final after the scaling)
-//   c < j : X[j][c] = (L^-1)[j][c]  (row j of the inverse, stored transposed in the upper triangle)
-// so a single multiplier m_c = S[c + j*LD] (c != j; Dinv[j] for c == j) drives both the Cholesky
-// rank-1 update (targets L[i][c], c > j) and the elimination that builds the inverse
-// (targets X[i][c], c <= j) of every row i > j.  The odd leading dimension keeps both the
-// column-walking and the row-walking accesses free of bank conflicts.
+// Diagonal block: Cholesky + inverse of a 128 x 128 block in one sweep by one workgroup.
 // ------------------------------------------------------------------------------------------------
 constexpr int PB = 128;
-constexpr int PLD = 129;
 
+// Register-resident formulation.  Thread (i = t & 127, ty = t >> 7) owns the 16 logical elements
+// (i, c = ty + 8k), k = 0..15, of the lower triangle in registers.  Element (i, c) holds the Cholesky
+// working entry A[i][c] until step c, where it becomes L[i][c] (stored to global at once) and the
+// register is re-used for X[i][c] = (L^-1)[i][c], which the same rank-1 sweep keeps eliminating:
+//     step j, row i > j:   c > j : A[i][c] -= L[i][j] * L[c][j]
+//                          c = j : L[i][j] = A[i][j] / l_jj  -> out;  X[i][j] = -L[i][j] / l_jj
+//                          c < j : X[i][c] -= L[i][j] * X[j][c]
+// Only the pivot column (owners: ty == j % 8) and the pivot row of the inverse (owners: i == j) cross
+// threads, through a double-buffered 128-entry LDS line: ONE barrier per column.  Scaling multiplies
+// by 1/l_jj exactly as LAPACK dpotf2 does (DSCAL with ONE/AJJ).
 __global__ __launch_bounds__(1024) void potf2_inv_kernel(double* A, int64_t lda, double* winv, int* info, int col0) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* S = sm;                 // PB * PLD
-  double* Dinv = sm + PB * PLD;   // PB
+  __shared__ double pub[2][PB + 2];  // [PB] = l_jj, [PB+1] = 1/l_jj, computed once by the pivot's owner
   const int t = threadIdx.x;
-  const int i = t & 127, ty = t >> 7;  // ty in 0..7
-  for (int c = ty; c < PB; c += 8) S[i + c * PLD] = (i >= c) ? A[i + (int64_t)c * lda] : 0.0;
-  if (t < PB) Dinv[t] = 1.0;
-  __syncthreads();
-
-  for (int j = 0; j < PB; ++j) {
-    const double d = S[j + j * PLD];
-    const bool bad = !(d > 0.0);
-    if (bad && t == 0) atomicCAS(info, 0, col0 + j + 1);  // LAPACK info: first non-PD leading minor
-    const double ljj = sqrt(d);
-    __syncthreads();  // everyone has read the pivot before it is overwritten
-    if (t < PB) {
-      if (t == j) { S[j + j * PLD] = ljj; Dinv[j] = 1.0 / ljj; }
-      else S[t + j * PLD] = S[t + j * PLD] / ljj;  // L[c][j] (c>j) and X[j][c] (c<j) alike
-    }
-    __syncthreads();
-    if (i > j) {
-      const double lij = S[i + j * PLD];
-      for (int c = ty; c <= i; c += 8) {
-        if (c > j) {
-          S[i + c * PLD] = fma(-lij, S[c + j * PLD], S[i + c * PLD]);
-        } else {
-          const double m = (c == j) ? Dinv[j] : S[c + j * PLD];
-          S[c + i * PLD] = fma(-lij, m, S[c + i * PLD]);
+  const int i = t & 127, ty = t >> 7;
+  double reg[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int c = ty + 8 * k;
+    reg[k] = (c <= i) ? A[i + (int64_t)c * lda] : 0.0;
+  }
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb) {     // compile-time register index of the pivot column: reg[kb]
+    for (int jj = 0; jj < 8; ++jj) {
+      const int j = kb * 8 + jj;
+      double* line = pub[j & 1];
+      // publish: pivot column A[.][j] (rows >= j) by its owners, pivot row X[j][.] (cols < j) by row j
+      if (ty == jj && i >= j) line[i] = reg[kb];
+      if (i == j) {
+        if (ty == jj) {
+          const double piv = reg[kb];
+          const double l = sqrt(piv);
+          line[PB] = l;
+          line[PB + 1] = 1.0 / l;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int c = ty + 8 * k;
+          if (c < j) line[c] = reg[k];
+        }
+      }
+      __syncthreads();
+      const double d = line[j];
+      if (!(d > 0.0) && t == 0) atomicCAS(info, 0, col0 + j + 1);  // LAPACK info: first non-PD leading minor
+      const double ljj = line[PB];
+      const double rinv = line[PB + 1];
+      if (i == j) {                      // row j is final: L[j][j], X[j][j] and the scaled X[j][c]
+        if (ty == jj) { A[j + (int64_t)j * lda] = ljj; reg[kb] = rinv; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int c = ty + 8 * k;
+          if (c < j) reg[k] *= rinv;
+        }
+      } else if (i > j) {
+        const double lij = line[i] * rinv;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int c = ty + 8 * k;
+          if (c > i) continue;
+          if (c == j) { A[i + (int64_t)j * lda] = lij; reg[k] = -lij * rinv; }
+          else reg[k] = fma(-lij, line[c] * rinv, reg[k]);
         }
       }
     }
-    __syncthreads();
   }
-  // write L (lower, in place) and Winv = L^-1 (dense 128x128, upper zero)
-  for (int c = ty; c < PB; c += 8) {
-    if (i >= c) A[i + (int64_t)c * lda] = S[i + c * PLD];
-    double w = 0.0;
-    if (i == c) w = Dinv[i];
-    else if (i > c) w = S[c + i * PLD];
-    winv[i + c * PB] = w;
+  // Winv = L^-1, dense 128 x 128 column-major, zero above the diagonal
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int c = ty + 8 * k;
+    winv[i + c * PB] = (c <= i) ? reg[k] : 0.0;
   }
 }
 
@@ -259,14 +278,8 @@ __global__ __launch_bounds__(256, 2) void trailing_kernel(double* packed, int64_
 }  // namespace
 
 int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* info_dev, int col0) {
-  const size_t smem = (size_t)(PB * PLD + PB) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
-  }
   ProfScope ps(s, PK_POTF2, 128.0 * 128 * 128 / 3 * 2, 8.0 * 3 * 128 * 128);
-  hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(1024), smem, s, A, lda, winv, info_dev, col0);
+  hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(1024), 0, s, A, lda, winv, info_dev, col0);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

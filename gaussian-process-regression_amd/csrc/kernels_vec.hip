@@ -32,80 +32,134 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return r;
 }
 
-// ---- forward substitution by 128-blocks --------------------------------------------------------
-// x_blk = Winv_blk * b_blk (in place), 128 threads
-__device__ __forceinline__ void diag_apply(const double* W, double* bblk, double* sh) {
-  const int i = threadIdx.x;
-  sh[i] = bblk[i];
+// ---- triangular solves with the packed factor, one NB-wide panel per step -------------------------
+// Forward  (L x = b):  for p = 0..P-1:  x_p = L_pp^-1 b_p  (one workgroup, using the 128-block inverses),
+//                      then b[below] -= L[below, panel p] * x_p  (one wide GEMV, thread groups per row).
+// Backward (L^T x = z): for p = P-1..0: x_p = L_pp^-T z_p, then z[q] -= L[panel-p rows, panel q cols]^T x_p for q < p.
+// Every reduction has a fixed order: results are bitwise reproducible.
+
+__device__ __forceinline__ double wave_sum(double s) {
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  return s;
+}
+
+// x_p = L_pp^-1 b_p in place.  1024 threads: (i = t & 127) x (ty = t >> 7, eight column groups).
+__global__ __launch_bounds__(1024) void trsv_diag_fwd(const double* packed, const double* winv, int64_t n_pad, int p, double* b) {
+  __shared__ double z[NB];
+  __shared__ double red[8][128];
+  const int t = threadIdx.x, i = t & 127, ty = t >> 7;
+  const int64_t ld = panel_ld(n_pad, p);
+  const double* pan = packed + panel_offset(n_pad, p);
+  double* bp = b + (int64_t)p * NB;
+  if (t < NB) z[t] = bp[t];
   __syncthreads();
-  double s = 0.0;
-  for (int c = 0; c <= i; ++c) s = fma(W[i + c * 128], sh[c], s);
-  bblk[i] = s;
-}
-
-__global__ __launch_bounds__(128) void trsv_fwd_first(const double* winv, double* b) {
-  __shared__ double sh[128];
-  diag_apply(winv, b, sh);
-}
-
-// after x_blk is known: b[rb] -= L[rb, blk] * x_blk for every block row rb > blk; the workgroup that
-// owns rb == blk+1 then finishes x_{blk+1}.
-__global__ __launch_bounds__(128) void trsv_fwd_step(const double* packed, const double* winv, int64_t n_pad, int blk, double* b) {
-  __shared__ double xs[128];
-  __shared__ double sh[128];
-  const int i = threadIdx.x;
-  const int64_t rb = (int64_t)blk + 1 + blockIdx.x;
-  xs[i] = b[(int64_t)blk * 128 + i];
-  __syncthreads();
-  const int64_t row = rb * 128 + i;
-  const double* Lr = packed_at(packed, n_pad, row, (int64_t)blk * 128);
-  const int64_t ld = panel_ld(n_pad, ((int64_t)blk * 128) / NB);
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  for (int c = 0; c < 128; c += 4) {
-    s0 = fma(Lr[(int64_t)c * ld], xs[c], s0);
-    s1 = fma(Lr[(int64_t)(c + 1) * ld], xs[c + 1], s1);
-    s2 = fma(Lr[(int64_t)(c + 2) * ld], xs[c + 2], s2);
-    s3 = fma(Lr[(int64_t)(c + 3) * ld], xs[c + 3], s3);
-  }
-  b[row] -= (s0 + s1) + (s2 + s3);
-  if (blockIdx.x == 0) {
-    __syncthreads();
-    diag_apply(winv + rb * 128 * 128, b + rb * 128, sh);
-  }
-}
-
-// ---- backward substitution (L^T) ---------------------------------------------------------------
-constexpr int BW_ROWS = 1024;  // rows of L per workgroup in the partial dot products
-
-// part[g][c] = sum over this workgroup's rows r (below block blk) of L[r][blk*128 + c] * x[r]
-__global__ __launch_bounds__(256) void trsv_bwd_partial(const double* packed, int64_t n_pad, int blk, const double* x, double* part) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t r0 = ((int64_t)blk + 1) * 128 + (int64_t)blockIdx.x * BW_ROWS;
-  const int64_t rend = (r0 + BW_ROWS < n_pad) ? r0 + BW_ROWS : n_pad;
-  const int64_t c0 = (int64_t)blk * 128;
-  const int64_t ld = panel_ld(n_pad, c0 / NB);
-  const double* Lb = packed_at(packed, n_pad, r0, c0);
-  for (int c = wave; c < 128; c += 4) {
-    const double* col = Lb + (int64_t)c * ld;
+  for (int j = 0; j < TPP; ++j) {
+    if (j > 0) {  // z_j -= L[j-th row block, columns 0 .. 128j) * x[0 .. 128j)
+      const double* Lr = pan + j * 128 + i;
+      double s = 0.0;
+      for (int c = ty; c < j * 128; c += 8) s = fma(Lr[(int64_t)c * ld], z[c], s);
+      red[ty][i] = s;
+      __syncthreads();
+      if (ty == 0) {
+        double v = z[j * 128 + i];
+        for (int g = 0; g < 8; ++g) v -= red[g][i];
+        z[j * 128 + i] = v;
+      }
+      __syncthreads();
+    }
+    const double* W = winv + ((int64_t)p * TPP + j) * 128 * 128;
     double s = 0.0;
-    for (int64_t r = r0 + lane; r < rend; r += 64) s = fma(col[r - r0], x[r], s);
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) part[(int64_t)blockIdx.x * 128 + c] = s;
+    for (int c = ty; c <= i; c += 8) s = fma(W[i + c * 128], z[j * 128 + c], s);
+    red[ty][i] = s;
+    __syncthreads();
+    if (ty == 0) {
+      double v = 0.0;
+      for (int g = 0; g < 8; ++g) v += red[g][i];
+      z[j * 128 + i] = v;
+    }
+    __syncthreads();
   }
+  if (t < NB) bp[t] = z[t];
 }
 
-// x_blk = Winv_blk^T * (z_blk - sum_g part[g])
-__global__ __launch_bounds__(128) void trsv_bwd_diag(const double* winv, int blk, int nparts, const double* part, double* x) {
-  __shared__ double sh[128];
-  const int i = threadIdx.x;
-  double v = x[(int64_t)blk * 128 + i];
-  for (int g = 0; g < nparts; ++g) v -= part[(int64_t)g * 128 + i];
-  sh[i] = v;
+// b[r] -= sum_c L[r, p*NB + c] * x_p[c] for the rows below panel p.  512 threads = 128 rows x 4 column groups.
+__global__ __launch_bounds__(512) void trsv_gemv_below(const double* packed, int64_t n_pad, int p, double* b) {
+  __shared__ double xs[NB];
+  __shared__ double red[4][128];
+  const int t = threadIdx.x, i = t & 127, g = t >> 7;
+  for (int c = t; c < NB; c += 512) xs[c] = b[(int64_t)p * NB + c];
   __syncthreads();
-  const double* W = winv + (int64_t)blk * 128 * 128;
-  double s = 0.0;
-  for (int c = i; c < 128; ++c) s = fma(W[c + i * 128], sh[c], s);
-  x[(int64_t)blk * 128 + i] = s;
+  const int64_t ld = panel_ld(n_pad, p);
+  const int64_t row = (int64_t)(p + 1) * NB + (int64_t)blockIdx.x * 128 + i;
+  const double* Lr = packed + panel_offset(n_pad, p) + (row - (int64_t)p * NB) + (int64_t)(g * (NB / 4)) * ld;
+  const double* xg = xs + g * (NB / 4);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+  for (int c = 0; c < NB / 4; c += 4) {
+    s0 = fma(Lr[(int64_t)c * ld], xg[c], s0);
+    s1 = fma(Lr[(int64_t)(c + 1) * ld], xg[c + 1], s1);
+    s2 = fma(Lr[(int64_t)(c + 2) * ld], xg[c + 2], s2);
+    s3 = fma(Lr[(int64_t)(c + 3) * ld], xg[c + 3], s3);
+  }
+  red[g][i] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0) b[row] -= (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+// x_p = L_pp^-T z_p in place.  16 waves; a wave owns columns w, w+16, ... and reduces over rows with its lanes.
+__global__ __launch_bounds__(1024) void trsv_diag_bwd(const double* packed, const double* winv, int64_t n_pad, int p, double* x) {
+  __shared__ double z[NB];
+  __shared__ double v[128];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int64_t ld = panel_ld(n_pad, p);
+  const double* pan = packed + panel_offset(n_pad, p);
+  double* xp = x + (int64_t)p * NB;
+  if (t < NB) z[t] = xp[t];
+  __syncthreads();
+  for (int j = TPP - 1; j >= 0; --j) {
+    // v[c] = z_j[c] - sum_{r >= 128(j+1)} L[r, 128j + c] * x[r]
+    for (int c = w; c < 128; c += 16) {
+      const double* col = pan + (int64_t)(j * 128 + c) * ld;
+      double s = 0.0;
+      for (int r = (j + 1) * 128 + lane; r < NB; r += 64) s = fma(col[r], z[r], s);
+      s = wave_sum(s);
+      if (lane == 0) v[c] = z[j * 128 + c] - s;
+    }
+    __syncthreads();
+    // x_j[c'] = sum_{c >= c'} W_j[c, c'] * v[c]
+    const double* W = winv + ((int64_t)p * TPP + j) * 128 * 128;
+    for (int cp = w; cp < 128; cp += 16) {
+      const double* wc = W + cp * 128;
+      double s = 0.0;
+      for (int c = lane; c < 128; c += 64)
+        if (c >= cp) s = fma(wc[c], v[c], s);
+      s = wave_sum(s);
+      if (lane == 0) z[j * 128 + cp] = s;
+    }
+    __syncthreads();
+  }
+  if (t < NB) xp[t] = z[t];
+}
+
+// z[q*NB + c] -= sum_r L[p*NB + r, q*NB + c] * x_p[r] for every earlier panel q < p.  Block = (q, 32 columns).
+__global__ __launch_bounds__(256) void trsv_gemvt_above(const double* packed, int64_t n_pad, int p, double* z) {
+  __shared__ double xs[NB];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  for (int c = t; c < NB; c += 256) xs[c] = z[(int64_t)p * NB + c];
+  __syncthreads();
+  const int q = blockIdx.x / (NB / 32), cg = blockIdx.x % (NB / 32);
+  const int64_t ld = panel_ld(n_pad, q);
+  const double* blk = packed + panel_offset(n_pad, q) + (int64_t)(p - q) * NB;  // rows of panel p inside panel q
+#pragma unroll 2
+  for (int k = 0; k < 8; ++k) {
+    const int c = cg * 32 + w * 8 + k;
+    const double* col = blk + (int64_t)c * ld;
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < NB; r += 64) s = fma(col[r + lane], xs[r + lane], s);
+    s = wave_sum(s);
+    if (lane == 0) z[(int64_t)q * NB + c] -= s;
+  }
 }
 
 // ---- row reductions over a tall column-major matrix --------------------------------------------
@@ -247,18 +301,19 @@ inline unsigned blocks(int64_t n, int per) { return (unsigned)((n + per - 1) / p
 int64_t rowreduce_splits(int64_t cols) { return (cols + RR_COLS - 1) / RR_COLS; }
 
 int launch_trsv(hipStream_t s, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose, double* work) {
-  const int nblk = (int)(n_pad / 128);
+  (void)work;
+  const int P = (int)(n_pad / NB);
   ProfScope ps(s, PK_TRSV, (double)n_pad * n_pad, 8.0 * 0.5 * n_pad * n_pad);
   if (!transpose) {
-    hipLaunchKernelGGL(trsv_fwd_first, dim3(1), dim3(128), 0, s, winv, b);
-    for (int blk = 0; blk + 1 < nblk; ++blk)
-      hipLaunchKernelGGL(trsv_fwd_step, dim3(nblk - 1 - blk), dim3(128), 0, s, packed, winv, n_pad, blk, b);
+    for (int p = 0; p < P; ++p) {
+      hipLaunchKernelGGL(trsv_diag_fwd, dim3(1), dim3(1024), 0, s, packed, winv, n_pad, p, b);
+      const int64_t below = n_pad - (int64_t)(p + 1) * NB;
+      if (below > 0) hipLaunchKernelGGL(trsv_gemv_below, dim3((unsigned)(below / 128)), dim3(512), 0, s, packed, n_pad, p, b);
+    }
   } else {
-    for (int blk = nblk - 1; blk >= 0; --blk) {
-      const int64_t below = n_pad - ((int64_t)blk + 1) * 128;
-      const int nparts = (int)((below + BW_ROWS - 1) / BW_ROWS);
-      if (nparts > 0) hipLaunchKernelGGL(trsv_bwd_partial, dim3(nparts), dim3(256), 0, s, packed, n_pad, blk, b, work);
-      hipLaunchKernelGGL(trsv_bwd_diag, dim3(1), dim3(128), 0, s, winv, blk, nparts, work, b);
+    for (int p = P - 1; p >= 0; --p) {
+      hipLaunchKernelGGL(trsv_diag_bwd, dim3(1), dim3(1024), 0, s, packed, winv, n_pad, p, b);
+      if (p > 0) hipLaunchKernelGGL(trsv_gemvt_above, dim3((unsigned)(p * (NB / 32))), dim3(256), 0, s, packed, n_pad, p, b);
     }
   }
   GPRC_LAUNCH_CHECK();

@@ -19,6 +19,7 @@ shape from tests/ -- nothing in this package falls back to the CPU.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from contextlib import contextmanager
 
 import numpy as np
@@ -109,7 +110,10 @@ class HipOps:
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         self.main_stream = torch.cuda.Stream(device=self.device)
-        self.side_stream = torch.cuda.Stream(device=self.device)
+        # high priority: the look-ahead panel work (a few small kernels) must be dispatched AHEAD of the tens of
+        # thousands of queued workgroups of the trailing update that runs beside it
+        prio = int(os.environ.get("GPRC_SIDE_PRIORITY", "-1"))
+        self.side_stream = torch.cuda.Stream(device=self.device, priority=prio)
         self.ctx_main = nat.Context(device, self.main_stream.cuda_stream)
         self.ctx_side = nat.Context(device, self.side_stream.cuda_stream)
         self.kernel_id = int(kernel_id)
@@ -206,8 +210,13 @@ class DistributedGPR:
     def __init__(self, ops, comm, lookahead=None):
         import os
         self.ops, self.comm = ops, comm
-        # GPRC_NO_LOOKAHEAD=1 serialises the panel factorisation behind the trailing update (measurement aid)
-        self.lookahead = (os.environ.get("GPRC_NO_LOOKAHEAD", "0") != "1") if lookahead is None else bool(lookahead)
+        # Look-ahead pays when there is a broadcast to hide (world > 1).  On ONE GPU the side-stream panel chain
+        # only competes with the trailing update for CUs (measured: potf2 0.17 -> 0.42 ms under contention, step
+        # time +0..25 %), so it is off by default there.  GPRC_LOOKAHEAD=0/1 overrides.
+        env = os.environ.get("GPRC_LOOKAHEAD")
+        if lookahead is None:
+            lookahead = (comm.world > 1) if env is None else (env == "1")
+        self.lookahead = bool(lookahead)
         g = ops.geom
         self.geom = g
         self.packed = ops.zeros(g.packed_size)
