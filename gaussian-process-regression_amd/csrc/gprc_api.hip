@@ -68,6 +68,9 @@ struct gprc_ctx {
   int* info_dev = nullptr;     // LAPACK info written by the diagonal-block kernel
   double* scal_dev = nullptr;  // 8 doubles of scalar results
   size_t chunk_bytes = (size_t)16 << 30;  // budget for one K_star^T chunk
+  // grow-only workspace slots (predict chunks): a multi-GiB hipMalloc/hipFree per call costs 100s of ms
+  double* ws[4] = {nullptr, nullptr, nullptr, nullptr};
+  int64_t ws_cap[4] = {0, 0, 0, 0};
   int64_t vt_pad = 0;                     // extra doubles in the chunk's leading dimension (keeps it off powers of two)
 };
 
@@ -137,6 +140,23 @@ struct Out {
     return 0;
   }
 };
+
+// workspace slot `slot` of the context, at least `count` doubles (contents undefined)
+int ws_get(gprc_ctx* ctx, int slot, int64_t count, double** out) {
+  if (count <= 0) count = 1;
+  if (ctx->ws_cap[slot] < count) {
+    if (ctx->ws[slot]) {
+      GPRC_HIP(hipStreamSynchronize(ctx->stream));
+      GPRC_HIP(hipFree(ctx->ws[slot]));
+      ctx->ws[slot] = nullptr;
+      ctx->ws_cap[slot] = 0;
+    }
+    GPRC_HIP(hipMalloc(&ctx->ws[slot], sizeof(double) * (size_t)count));
+    ctx->ws_cap[slot] = count;
+  }
+  *out = ctx->ws[slot];
+  return 0;
+}
 
 struct DevMem {  // scoped device allocation
   double* p = nullptr;
@@ -363,6 +383,8 @@ int gprc_ctx_destroy(gprc_ctx* ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < 4; ++i)
+    if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   if (ctx->info_dev) (void)hipFree(ctx->info_dev);
   if (ctx->scal_dev) (void)hipFree(ctx->scal_dev);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -474,10 +496,10 @@ int gprc_gpr_predict(gprc_model* m, const double* X_star, int64_t ns, int pointw
 
   const int64_t rows = pointwise ? chunk_rows(ctx, n_pad, ns) : pad_up(ns, 128);
   const int64_t ldv = rows + ctx->vt_pad;  // one leading dimension for every chunk
-  DevMem vt, red, tmp;
-  GPRC_TRY(vt.alloc(ldv * n_pad));
-  GPRC_TRY(red.alloc(rows * rowreduce_splits(n_pad)));
-  GPRC_TRY(tmp.alloc(3 * rows));
+  struct { double* p; } vt, red, tmp;
+  GPRC_TRY(ws_get(ctx, 0, ldv * n_pad, &vt.p));
+  GPRC_TRY(ws_get(ctx, 1, rows * rowreduce_splits(n_pad), &red.p));
+  GPRC_TRY(ws_get(ctx, 2, 3 * rows, &tmp.p));
   double* mean_c = tmp.p;
   double* ss_c = tmp.p + rows;
   double* kss_c = tmp.p + 2 * rows;
@@ -497,8 +519,8 @@ int gprc_gpr_predict(gprc_model* m, const double* X_star, int64_t ns, int pointw
     }
   } else {
     const int64_t m_pad = rows;
-    DevMem cov;
-    GPRC_TRY(cov.alloc(m_pad * m_pad));
+    struct { double* p; } cov;
+    GPRC_TRY(ws_get(ctx, 3, m_pad * m_pad, &cov.p));
     GPRC_TRY(launch_fill(s, m->ks, xs.dev, ns, m->X, n, d, vt.p, ldv, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0));
     GPRC_TRY(launch_row_reduce(s, vt.p, ldv, m_pad, n_pad, m->alpha, mean_c, red.p));
     GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt.p, ldv, m_pad));
@@ -661,10 +683,10 @@ int gprc_gpc_predict_latent(gprc_model* m, const double* X_star, int64_t ns, dou
   GPRC_TRY(vf.set(Vfs_out, ns));
   const int64_t rows = chunk_rows(ctx, n_pad, ns);
   const int64_t ldv = rows + ctx->vt_pad;
-  DevMem vt, red, tmp;
-  GPRC_TRY(vt.alloc(ldv * n_pad));
-  GPRC_TRY(red.alloc(rows * rowreduce_splits(n_pad)));
-  GPRC_TRY(tmp.alloc(3 * rows));
+  struct { double* p; } vt, red, tmp;
+  GPRC_TRY(ws_get(ctx, 0, ldv * n_pad, &vt.p));
+  GPRC_TRY(ws_get(ctx, 1, rows * rowreduce_splits(n_pad), &red.p));
+  GPRC_TRY(ws_get(ctx, 2, 3 * rows, &tmp.p));
   double *mean_c = tmp.p, *ss_c = tmp.p + rows, *kss_c = tmp.p + 2 * rows;
   for (int64_t s0 = 0; s0 < ns; s0 += rows) {
     const int64_t mcur = (ns - s0 < rows) ? ns - s0 : rows;

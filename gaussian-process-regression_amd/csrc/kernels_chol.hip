@@ -119,11 +119,14 @@ __device__ __forceinline__ void read_ops(const double* Ac, const double* Bc, int
 #pragma unroll
   for (int n = 0; n < 4; ++n) b[n] = Bc[kk * 4 * G_LDT + n * 16];
 }
+// NEG = 1 sets the f64 MFMA's negate-A bit (the BLGP field is the NEG set on f64 MFMA; verified on gfx950 by
+// tools/microbench/mfma_neg.hip): acc = acc - op_a * op_b, exactly.
+template <int NEG>
 __device__ __forceinline__ void mma_step(const double (&a)[4], const double (&b)[4], double4_t (&acc)[4][4]) {
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[n], a[m], acc[m][n], 0, 0, 0);
+    for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[n], a[m], acc[m][n], 0, 0, NEG);
 }
 
 // LDS-DMA of one k-tile of both strips: wave w moves k-slices w, w+4, w+8, w+12 of A and of B; one
@@ -149,11 +152,17 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
   double* As = smem;
   double* Bs = smem + 2 * G_BUF;
 
+  // C -= A*B^T: the accumulators START as the C tile (its loads fly with the first DMA) and every MFMA
+  // subtracts, so the epilogue is stores only.  SET: accumulators start at zero, plain products.
+  constexpr int NEG = SET ? 0 : 1;
+  double* Cw = C + (wr * 64 + fr) + (int64_t)(wc * 64 + fk) * ldc;
   double4_t acc[4][4];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int n = 0; n < 4; ++n)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m][n][r] = SET ? 0.0 : Cw[m * 16 + (int64_t)(n * 16 + 4 * r) * ldc];
 
   const double* Ag = A + 2 * lane + (int64_t)wave * lda;  // this lane's 16 bytes of k-slice `wave`
   const double* Bg = B + 2 * lane + (int64_t)wave * ldb;
@@ -179,11 +188,11 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
     const double* Ac = As + cur + wr * 64 + foff;
     const double* Bc = Bs + cur + wc * 64 + foff;
     read_ops(Ac, Bc, 1, a1, b1);
-    mma_step(a0, b0, acc);
+    mma_step<NEG>(a0, b0, acc);
     read_ops(Ac, Bc, 2, a0, b0);
-    mma_step(a1, b1, acc);
+    mma_step<NEG>(a1, b1, acc);
     read_ops(Ac, Bc, 3, a1, b1);
-    mma_step(a0, b0, acc);
+    mma_step<NEG>(a0, b0, acc);
     if (kt + 1 < KT) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 has landed (this wave's share)
       __syncthreads();                                   // ... everyone's share; and buffer `cur` is drained
@@ -194,20 +203,15 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
       }
       read_ops(As + nxt + wr * 64 + foff, Bs + nxt + wc * 64 + foff, 0, a0, b0);
     }
-    mma_step(a1, b1, acc);
+    mma_step<NEG>(a1, b1, acc);
   }
 
-  double* Cw = C + (wr * 64 + fr) + (int64_t)(wc * 64 + fk) * ldc;
 #pragma unroll
   for (int n = 0; n < 4; ++n)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        double* p = Cw + m * 16 + (int64_t)(n * 16 + 4 * r) * ldc;
-        if (SET) *p = acc[m][n][r];
-        else *p = *p - acc[m][n][r];
-      }
+      for (int m = 0; m < 4; ++m) Cw[m * 16 + (int64_t)(n * 16 + 4 * r) * ldc] = acc[m][n][r];
 }
 
 // blockIdx -> logical id so that each XCD (blocks b, b+8, ... share one) owns a contiguous id range
@@ -287,6 +291,9 @@ int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* i
 static int ensure_gemm_attrs() {
   static bool done = false;
   if (done) return 0;
+
+
+
   const int smem = (int)(G_SMEM_DOUBLES * sizeof(double));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<PK_GEMM_INNER>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<PK_SOLVE_UPDATE>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
