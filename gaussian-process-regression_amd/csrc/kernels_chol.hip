@@ -25,20 +25,24 @@ namespace {
 constexpr int PB = 128;
 
 // Register-resident formulation.  Thread (i = t & 127, ty = t >> 7) owns the 16 logical elements
-// (i, c = ty + 8k), k = 0..15, of the lower triangle in registers.  Element (i, c) holds the Cholesky
-// working entry A[i][c] until step c, where it becomes L[i][c] (stored to global at once) and the
-// register is re-used for X[i][c] = (L^-1)[i][c], which the same rank-1 sweep keeps eliminating:
+// (i, c = ty + 8k), k = 0..15, in registers.  Element (i, c), c <= i, holds the Cholesky working entry
+// A[i][c] until step c, where it becomes L[i][c] (stored to global at once) and the register is re-used for
+// the UNSCALED inverse entry Y[i][c] = l_ii * (L^-1)[i][c], which the same rank-1 sweep keeps eliminating:
 //     step j, row i > j:   c > j : A[i][c] -= L[i][j] * L[c][j]
-//                          c = j : L[i][j] = A[i][j] / l_jj  -> out;  X[i][j] = -L[i][j] / l_jj
-//                          c < j : X[i][c] -= L[i][j] * X[j][c]
-// Only the pivot column (owners: ty == j % 8) and the pivot row of the inverse (owners: i == j) cross
-// threads, through a double-buffered 128-entry LDS line: ONE barrier per column.  Scaling multiplies
-// by 1/l_jj exactly as LAPACK dpotf2 does (DSCAL with ONE/AJJ).
+//                          c = j : L[i][j] = A[i][j] / l_jj  -> out;  Y[i][j] = -L[i][j] / l_jj
+//                          c < j : Y[i][c] -= L[i][j] * X[j][c],   X[j][c] = Y[j][c] / l_jj
+// With m_c = line[c] / l_jj (line = the published pivot column below j and pivot row of Y left of j) both
+// updates are the SAME fma, so the sweep is branch-free: rows i <= j use a zero multiplier, dead elements
+// (c > i) are updated harmlessly and never read, and row scaling is deferred to the final store.
+// Only the pivot column (owners: ty == j % 8) and row j of Y (owners: i == j) cross threads, through a
+// double-buffered LDS line: ONE barrier per column.  Scaling multiplies by 1/l_jj as LAPACK dpotf2 does.
 __global__ __launch_bounds__(1024) void potf2_inv_kernel(double* A, int64_t lda, double* winv, int* info, int col0) {
   __shared__ double pub[2][PB + 2];  // [PB] = l_jj, [PB+1] = 1/l_jj, computed once by the pivot's owner
   const int t = threadIdx.x;
   const int i = t & 127, ty = t >> 7;
+  const int wave_last_row = (t & 64) + 63;   // rows of this wave: (t & 64) .. +63
   double reg[16];
+  double my_rinv = 1.0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const int c = ty + 8 * k;
@@ -46,15 +50,15 @@ __global__ __launch_bounds__(1024) void potf2_inv_kernel(double* A, int64_t lda,
   }
 #pragma unroll
   for (int kb = 0; kb < 16; ++kb) {     // compile-time register index of the pivot column: reg[kb]
+#pragma unroll 1
     for (int jj = 0; jj < 8; ++jj) {
       const int j = kb * 8 + jj;
       double* line = pub[j & 1];
-      // publish: pivot column A[.][j] (rows >= j) by its owners, pivot row X[j][.] (cols < j) by row j
+      // publish: pivot column A[.][j] (rows >= j) by its owners, row j of Y (cols < j) by row j
       if (ty == jj && i >= j) line[i] = reg[kb];
       if (i == j) {
         if (ty == jj) {
-          const double piv = reg[kb];
-          const double l = sqrt(piv);
+          const double l = sqrt(reg[kb]);
           line[PB] = l;
           line[PB + 1] = 1.0 / l;
         }
@@ -65,34 +69,39 @@ __global__ __launch_bounds__(1024) void potf2_inv_kernel(double* A, int64_t lda,
         }
       }
       __syncthreads();
+      if (wave_last_row < j) continue;   // wave-uniform: every row of this wave is final
       const double d = line[j];
       if (!(d > 0.0) && t == 0) atomicCAS(info, 0, col0 + j + 1);  // LAPACK info: first non-PD leading minor
       const double ljj = line[PB];
       const double rinv = line[PB + 1];
-      if (i == j) {                      // row j is final: L[j][j], X[j][j] and the scaled X[j][c]
-        if (ty == jj) { A[j + (int64_t)j * lda] = ljj; reg[kb] = rinv; }
+      const bool below = i > j;
+      const double lij = below ? line[i] * rinv : 0.0;
+      const double mult = -lij * rinv;   // -(L[i][j] / l_jj): one fma per element against the UNSCALED line
+      if (wave_last_row >= 64) {
+        double lv[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const int c = ty + 8 * k;
-          if (c < j) reg[k] *= rinv;
-        }
-      } else if (i > j) {
-        const double lij = line[i] * rinv;
+        for (int k = 0; k < 16; ++k) lv[k] = line[ty + 8 * k];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const int c = ty + 8 * k;
-          if (c > i) continue;
-          if (c == j) { A[i + (int64_t)j * lda] = lij; reg[k] = -lij * rinv; }
-          else reg[k] = fma(-lij, line[c] * rinv, reg[k]);
-        }
+        for (int k = 0; k < 16; ++k) reg[k] = fma(mult, lv[k], reg[k]);
+      } else {                           // rows 0..63: columns c = ty + 8k > 63 are all above the diagonal
+        double lv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lv[k] = line[ty + 8 * k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) reg[k] = fma(mult, lv[k], reg[k]);
       }
+      if (ty == jj) {                    // the pivot column itself: final L[i][j], first inverse entry
+        if (below) { A[i + (int64_t)j * lda] = lij; reg[kb] = mult; }
+        else if (i == j) { A[j + (int64_t)j * lda] = ljj; reg[kb] = 1.0; }
+      }
+      if (i == j) my_rinv = rinv;
     }
   }
-  // Winv = L^-1, dense 128 x 128 column-major, zero above the diagonal
+  // Winv = L^-1 = diag(1/l_ii) * Y, dense 128 x 128 column-major, zero above the diagonal
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const int c = ty + 8 * k;
-    winv[i + c * PB] = (c <= i) ? reg[k] : 0.0;
+    winv[i + c * PB] = (c <= i) ? reg[k] * my_rinv : 0.0;
   }
 }
 
