@@ -178,30 +178,44 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
   const int srow = wave * G_LDT;                          // LDS row of that slice (wave-uniform)
   const int foff = fr + fk * G_LDT;                       // this lane's MFMA operand element
 
-  // Software pipeline.  Invariant at the top of iteration kt: tile kt is visible in buffer kt&1, the DMA
-  // of tile kt+1 is in flight into the other buffer, and a0/b0 hold the operands of (kt, k-step 0).
-  // The barrier sits in front of the LAST k-step's MFMAs: by then every wave holds its last operands of
-  // tile kt in registers, so the buffer can be handed to the DMA of tile kt+2 while 16 MFMAs still run,
-  // and that DMA has a full tile of MFMAs (64 x 64 cycles) to land.
+  // Software pipeline, operand reads TWO k-steps ahead.  Four named operand sets (one per k-step of a tile).
+  // Every k-step is:  s_waitcnt lgkmcnt(0)  ->  issue the reads of step +2  ->  16 MFMAs of this step.
+  // The wait therefore only ever covers reads issued one whole MFMA block (>= 1000 cycles) earlier; with the
+  // reads issued right in front of the compiler's own lgkmcnt(0) they were waited for on the spot.
+  //   step (t,0): reads (t,2)          step (t,1): reads (t,3)   <- last LDS reads of tile t's buffer
+  //   step (t,2): vmcnt(0) + barrier [tile t+1 landed, tile t's buffer drained]; DMA tile t+2; reads (t+1,0)
+  //   step (t,3): reads (t+1,1)
+  // so a DMA has 64 MFMAs (4096 cycles) to land, as before.
+  constexpr int LGKM0 = 0xC07F;  // s_waitcnt lgkmcnt(0), vmcnt/expcnt untouched
   const int KT = K / G_KB;
   dma_ktile(Ag, lda, Bg, ldb, As + srow, Bs + srow);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // vmcnt(0) through the BUILTIN, not inline asm, so that the compiler's waitcnt pass knows the C-tile loads
+  // above have completed and does not re-wait vmcnt(0) (draining fresh DMAs) inside the loop.  0x0F70 = vmcnt(0).
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   if (KT > 1) dma_ktile(Ag + (int64_t)G_KB * lda, lda, Bg + (int64_t)G_KB * ldb, ldb, As + G_BUF + srow, Bs + G_BUF + srow);
   Ag += (int64_t)2 * G_KB * lda;  // next tile to request: kt + 2
   Bg += (int64_t)2 * G_KB * ldb;
-  double a0[4], b0[4], a1[4], b1[4];
+  double a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
   read_ops(As + wr * 64 + foff, Bs + wc * 64 + foff, 0, a0, b0);
+  read_ops(As + wr * 64 + foff, Bs + wc * 64 + foff, 1, a1, b1);
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = (kt & 1) * G_BUF, nxt = G_BUF - cur;
     const double* Ac = As + cur + wr * 64 + foff;
     const double* Bc = Bs + cur + wc * 64 + foff;
-    read_ops(Ac, Bc, 1, a1, b1);
+    const double* An = As + nxt + wr * 64 + foff;
+    const double* Bn = Bs + nxt + wc * 64 + foff;
+    // sched_barrier(0) after every MFMA block: register-only MFMAs otherwise drift across the explicit waits and
+    // the compiler merges blocks, putting the reads back in front of a wait
+    __builtin_amdgcn_s_waitcnt(LGKM0);
+    read_ops(Ac, Bc, 2, a2, b2);
     mma_step<NEG>(a0, b0, acc);
-    read_ops(Ac, Bc, 2, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(LGKM0);
+    read_ops(Ac, Bc, 3, a3, b3);
     mma_step<NEG>(a1, b1, acc);
-    read_ops(Ac, Bc, 3, a1, b1);
-    mma_step<NEG>(a0, b0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(LGKM0);
     if (kt + 1 < KT) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 has landed (this wave's share)
       __syncthreads();                                   // ... everyone's share; and buffer `cur` is drained
@@ -210,9 +224,14 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
         Ag += (int64_t)G_KB * lda;
         Bg += (int64_t)G_KB * ldb;
       }
-      read_ops(As + nxt + wr * 64 + foff, Bs + nxt + wc * 64 + foff, 0, a0, b0);
+      read_ops(An, Bn, 0, a0, b0);
     }
-    mma_step<NEG>(a1, b1, acc);
+    mma_step<NEG>(a2, b2, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(LGKM0);
+    if (kt + 1 < KT) read_ops(An, Bn, 1, a1, b1);
+    mma_step<NEG>(a3, b3, acc);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
 #pragma unroll
