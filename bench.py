@@ -216,6 +216,16 @@ def main():
         dom = prof[dom_name]
         achieved = dom["flops"] / dom["ms"] * 1e-9 if dom["ms"] > 0 else 0.0
         symbol = {"solve_update_k512": "gemm_nt_kernel<5>", "trailing_update": "trailing_kernel"}[dom_name]
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
+        # comes from the separate rocprofv3 --pmc passes of the same command stored under profiles/ (see the JSON's
+        # `source`), per launch and corrected as MI355X_MICROARCH.md prescribes; null when no matching profile.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_c4_pmc_traffic.json")))
+            if pm["kernel"] == symbol and pm["workload"] == args.workload and pm["n_gpus"] == world and not args.n and not args.nstar:
+                traffic = pm["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "GPR predict-step achieved fp64 TFLOP/s (kernel fill + Cholesky + solves + mean/variance), n x n sqexp",
             "value": round(flops / (elapsed / args.steps) * 1e-12, 4),
@@ -233,7 +243,8 @@ def main():
                        "n": n, "d": d, "n_star": ns, "kernel": kname, "kernel_params": params,
                        "parallelism": f"1-D block-cyclic 512-column panels over {world} GPU(s), test points sliced"},
             "roofline": {"bound": "mfma", "kernel": symbol, "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per launch (PMC, separate pass)", "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["count"], 1)),
                          "launches": dom["count"], "avg_launch_ms": round(dom["ms"] / max(dom["count"], 1), 4)},
             "kernels": kernels,
             "frac_of_fp64_peak_end_to_end": round(flops / (elapsed / args.steps) * 1e-12 / (FP64_MFMA_PEAK_TFLOPS * world), 4),
