@@ -67,6 +67,8 @@ PROTOTYPES = {
     "gprc_gpc_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, C.c_double, C.c_int, C.c_int, C.POINTER(_vp),
                                C.POINTER(C.c_int)]),
     "gprc_gpc_predict_latent": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "gprc_gpc_predict_class": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "gprc_class_probability": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "gprc_gpc_get_f_hat": (C.c_int, [_vp, _vp]),
     "gprc_gpc_get_logq": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "gprc_panel_width": (_i64, []),

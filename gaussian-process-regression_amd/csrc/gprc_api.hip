@@ -707,6 +707,33 @@ int gprc_gpc_predict_latent(gprc_model* m, const double* X_star, int64_t ns, dou
   return 0;
 }
 
+int gprc_class_probability(gprc_ctx* ctx, const double* fs_bar, const double* Vfs, int64_t n, double* prob_out) {
+  GPRC_TRY(use_device(ctx));
+  if (n < 0 || (n > 0 && (!fs_bar || !Vfs || !prob_out))) { set_error("class_probability: bad arguments"); return GPRC_ERR_ARG; }
+  if (n == 0) return 0;
+  hipStream_t s = ctx->stream;
+  In a, b;
+  Out o;
+  GPRC_TRY(a.set(s, fs_bar, n));
+  GPRC_TRY(b.set(s, Vfs, n));
+  GPRC_TRY(o.set(prob_out, n));
+  GPRC_TRY(launch_gpc_class_prob(s, a.dev, b.dev, o.dev, n));
+  GPRC_TRY(o.finish(s));
+  GPRC_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int gprc_gpc_predict_class(gprc_model* m, const double* X_star, int64_t ns, double* prob_out) {
+  if (!m || m->type != MODEL_GPC) { set_error("predict_class: not a GPC model"); return GPRC_ERR_ARG; }
+  if (ns < 0 || (ns > 0 && (!X_star || !prob_out))) { set_error("predict_class: bad arguments"); return GPRC_ERR_ARG; }
+  if (ns == 0) return 0;
+  DevMem lat;
+  GPRC_TRY(use_device(m->ctx));
+  GPRC_TRY(lat.alloc(2 * ns));
+  GPRC_TRY(gprc_gpc_predict_latent(m, X_star, ns, lat.p, lat.p + ns));   // device outputs: used in place
+  return gprc_class_probability(m->ctx, lat.p, lat.p + ns, ns, prob_out);
+}
+
 int gprc_gpc_get_f_hat(gprc_model* m, double* f_hat_out) {
   if (!m || m->type != MODEL_GPC) { set_error("not a GPC model"); return GPRC_ERR_ARG; }
   return copy_out_vec(m, m->f_hat, f_hat_out, m->n);

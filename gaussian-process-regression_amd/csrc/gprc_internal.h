@@ -102,6 +102,7 @@ int launch_gpc_objective(hipStream_t s, const double* a, const double* f, const 
 int launch_gpc_build_B(hipStream_t s, const double* Kfull, int64_t n_pad, const double* sw, double* packed);
 int launch_gpc_grad(hipStream_t s, const double* f, const double* y, int64_t n, double* g, double* sw);           // g=(y+1)/2-P
 int launch_scale_cols(hipStream_t s, double* vt, int64_t ld, int64_t rows, int64_t cols, const double* colscale); // vt[i,j]*=colscale[j]
+int launch_gpc_class_prob(hipStream_t s, const double* fs, const double* vf, double* out, int64_t n);              // R/GPCclass.R:116-117
 int launch_diag_sum(hipStream_t s, const double* packed, int64_t n_pad, int64_t n, double* out);                  // sum(diag(L))
 
 }  // namespace gprc

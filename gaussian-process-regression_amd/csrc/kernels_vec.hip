@@ -294,6 +294,62 @@ __global__ __launch_bounds__(256) void scale_cols_kernel(double* vt, int64_t ld,
   for (int64_t j = blockIdx.y; j < cols; j += gridDim.y) vt[i + j * ld] *= cs[j];
 }
 
+// ---- GPC class probability: P(y* = +1) = integral of sigmoid(z) * N(z; mean = fs_bar, sd = Vfs) dz ------------
+// Replaces the per-point stats::integrate() call of R/GPCclass.R:116-117 (QUADPACK dqagi, rel.tol 1.2e-4); the
+// reference passes the VARIANCE Vfs as dnorm's sd -- kept.  Composite 16-point Gauss-Legendre, ~1e-14 accurate:
+//   sd < 1 : in t = (z - mu)/sd over [-12, 12] (24 panels): the Gaussian sets the scale, sigmoid(mu + sd t) is slow;
+//   sd >= 1: in z over [-40, 40] n [mu - 12 sd, mu + 12 sd] with panels <= 2 wide: the sigmoid sets the scale; beyond
+//            z = 40 sigmoid is 1 to 4e-18 and the remaining Gaussian mass is added in closed form (erfc).
+// sd <= 0 or NaN -> NaN (dnorm is undefined / a point mass there and integrate() stops in the reference).
+__constant__ double GL_X[16] = {
+    -9.89400934991649939e-01, -9.44575023073232600e-01, -8.65631202387831755e-01, -7.55404408355002999e-01,
+    -6.17876244402643771e-01, -4.58016777657227370e-01, -2.81603550779258915e-01, -9.50125098376374544e-02,
+    9.50125098376374544e-02,  2.81603550779258915e-01,  4.58016777657227370e-01,  6.17876244402643771e-01,
+    7.55404408355002999e-01,  8.65631202387831755e-01,  9.44575023073232600e-01,  9.89400934991649939e-01};
+__constant__ double GL_W[16] = {
+    2.71524594117540374e-02, 6.22535239386477063e-02, 9.51585116824925914e-02, 1.24628971255534030e-01,
+    1.49595988816576764e-01, 1.69156519395002619e-01, 1.82603415044923612e-01, 1.89450610455068585e-01,
+    1.89450610455068585e-01, 1.82603415044923612e-01, 1.69156519395002619e-01, 1.49595988816576764e-01,
+    1.24628971255534030e-01, 9.51585116824925914e-02, 6.22535239386477063e-02, 2.71524594117540374e-02};
+
+__global__ __launch_bounds__(64) void gpc_class_prob_kernel(const double* fs, const double* vf, double* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const double mu = fs[i], sd = vf[i];
+  if (!(sd > 0.0) || !(mu == mu)) { out[i] = __builtin_nan(""); return; }
+  const double inv_sqrt_2pi = 0.3989422804014326779;
+  double acc = 0.0;
+  if (sd < 1.0) {
+    for (int p = 0; p < 24; ++p) {
+      const double c = -11.5 + p;  // panel [c - 0.5, c + 0.5]
+      double s = 0.0;
+      for (int q = 0; q < 16; ++q) {
+        const double t = c + 0.5 * GL_X[q];
+        s = fma(GL_W[q], sigmoid(mu + sd * t) * exp(-0.5 * t * t), s);
+      }
+      acc = fma(0.5 * inv_sqrt_2pi, s, acc);
+    }
+  } else {
+    const double lo = fmax(-40.0, mu - 12.0 * sd), hi = fmin(40.0, mu + 12.0 * sd);
+    if (hi > lo) {
+      const int np = (int)ceil((hi - lo) * 0.5);
+      const double h = (hi - lo) / np;
+      for (int p = 0; p < np; ++p) {
+        const double c = lo + (p + 0.5) * h;
+        double s = 0.0;
+        for (int q = 0; q < 16; ++q) {
+          const double z = c + 0.5 * h * GL_X[q];
+          const double t = (z - mu) / sd;
+          s = fma(GL_W[q], sigmoid(z) * exp(-0.5 * t * t), s);
+        }
+        acc = fma(0.5 * h * inv_sqrt_2pi / sd, s, acc);
+      }
+    }
+    if (mu + 12.0 * sd > 40.0) acc += 0.5 * erfc((fmax(40.0, lo) - mu) / (sd * 1.4142135623730951));  // sigmoid = 1 above z = 40
+  }
+  out[i] = acc;
+}
+
 inline unsigned blocks(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
@@ -386,6 +442,12 @@ int launch_gpc_objective(hipStream_t s, const double* a, const double* f, const 
 int launch_gpc_build_B(hipStream_t s, const double* Kfull, int64_t n_pad, const double* sw, double* packed) {
   const unsigned gy = (unsigned)(n_pad < 16384 ? n_pad : 16384);
   hipLaunchKernelGGL(gpc_build_B_kernel, dim3(blocks(n_pad, 256), gy), dim3(256), 0, s, Kfull, n_pad, sw, packed);
+  GPRC_LAUNCH_CHECK();
+  return 0;
+}
+int launch_gpc_class_prob(hipStream_t s, const double* fs, const double* vf, double* out, int64_t n) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gpc_class_prob_kernel, dim3(blocks(n, 64)), dim3(64), 0, s, fs, vf, out, n);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

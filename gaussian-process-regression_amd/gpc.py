@@ -2,9 +2,9 @@
 
 `GPC$new(X, y, k, epsilon)` runs the Laplace/IRLS mode search on the GPU (kernel fill once, then per
 iteration B = I + sqrt(W) K sqrt(W), its Cholesky, two triangular solves and two K-matvecs);
-`predict_class` gets fs_bar / Vfs from the GPU (R/GPCclass.R:109-115) and then evaluates the
-reference's per-point 1-D integral (:116-117) on the host with QUADPACK, as the reference does with
-stats::integrate -- that integral is the caller of the hot path (SURVEY 8f), not part of it.
+`predict_class` gets fs_bar / Vfs from the GPU (R/GPCclass.R:109-115) and evaluates the reference's
+per-point 1-D integral (:116-117, stats::integrate there) as one batched device quadrature kernel
+(SURVEY 8f rank 3); the reference's own QUADPACK method stays available as `integrator="quadpack"`.
 Reference quirks are reproduced: logq uses sum(diag(L)) (:103), the integral passes the *variance* Vfs
 as dnorm's sd (:117), and the stop rule of :90-91 (`least_objective + 10 < objective`, which fires when
 the maximised objective IMPROVES by more than 10 over iteration 1) raises "Apparently does not converge."
@@ -75,12 +75,26 @@ class GPC:
         nat.check(nat.lib().gprc_gpc_predict_latent(self._model, Xs.ctypes.data, ns, fs.ctypes.data, vf.ctypes.data))
         return fs, vf
 
-    def predict_class(self, X_star):
-        """GPC$predict_class(X_star)  --  R/GPCclass.R:108-118: P(y* = +1 | x*) per test point."""
+    def predict_class(self, X_star, integrator="native"):
+        """GPC$predict_class(X_star)  --  R/GPCclass.R:108-118: P(y* = +1 | x*) per test point.
+        integrator="native": the batched device quadrature (gprc_gpc_predict_class);
+        integrator="quadpack": the reference's own method on the host (QUADPACK QAGI through scipy, as
+        stats::integrate), kept as a cross-check.  Both reproduce sd = Vfs[i] (sic, :117)."""
+        if integrator == "native":
+            Xs = np.asarray(X_star, dtype=np.float64)
+            Xs = as_points(Xs)
+            if Xs.shape[0] != self._X.shape[0]:
+                raise ValueError("X_star must have nrow(X) rows")
+            ns = Xs.shape[1]
+            out = np.empty(ns)
+            nat.check(nat.lib().gprc_gpc_predict_class(self._model, Xs.ctypes.data, ns, out.ctypes.data))
+            return out
+        if integrator != "quadpack":
+            raise ValueError("integrator must be 'native' or 'quadpack'")
         from scipy import integrate, stats
         fs, vf = self.predict_latent(X_star)
         out = np.empty(fs.size)
-        for i in range(fs.size):  # :116-117, sd = Vfs[i] (sic)
+        for i in range(fs.size):  # :116-117
             mu, sd = fs[i], vf[i]
             out[i] = integrate.quad(lambda z: (1.0 / (1.0 + np.exp(-z))) * stats.norm.pdf(z, loc=mu, scale=sd),
                                     -np.inf, np.inf)[0]

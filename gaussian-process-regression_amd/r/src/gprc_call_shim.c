@@ -132,7 +132,18 @@ SEXP gprc_R_gpc_fit(SEXP kernel, SEXP params, SEXP X, SEXP y, SEXP epsilon) {
   return res;
 }
 
-/* fs_bar, Vfs of GPC$predict_class  --  R/GPCclass.R:109-115; the integrate() loop stays in R */
+/* whole GPC$predict_class on the device (latent stage + batched class-probability quadrature)  --  R/GPCclass.R:108-118 */
+SEXP gprc_R_gpc_predict_class(SEXP handle, SEXP X_star) {
+  gprc_model* m = model_of(handle);
+  const int64_t ns = Rf_ncols(X_star);
+  SEXP res = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t)ns));
+  int rc = gprc_gpc_predict_class(m, REAL(X_star), ns, REAL(res));
+  UNPROTECT(1);
+  if (rc != 0) Rf_error("gprc: %s", gprc_last_error());
+  return res;
+}
+
+/* fs_bar, Vfs of GPC$predict_class  --  R/GPCclass.R:109-115; for callers that keep the integrate() loop in R */
 SEXP gprc_R_gpc_predict_latent(SEXP handle, SEXP X_star) {
   gprc_model* m = model_of(handle);
   const int64_t ns = Rf_ncols(X_star);
@@ -156,6 +167,7 @@ static const R_CallMethodDef call_methods[] = {
     {"gprc_R_model_L", (DL_FUNC)&gprc_R_model_L, 1},
     {"gprc_R_gpc_fit", (DL_FUNC)&gprc_R_gpc_fit, 5},
     {"gprc_R_gpc_predict_latent", (DL_FUNC)&gprc_R_gpc_predict_latent, 2},
+    {"gprc_R_gpc_predict_class", (DL_FUNC)&gprc_R_gpc_predict_class, 2},
     {"gprc_R_device_count", (DL_FUNC)&gprc_R_device_count, 0},
     {NULL, NULL, 0}};
 

@@ -129,6 +129,13 @@ GPRC_API int gprc_gpc_fit(gprc_ctx* ctx, int kernel, const double* params, int n
 /* the hot part of GPC$predict_class (R/GPCclass.R:109-115): fs_bar and Vfs for X_star. */
 GPRC_API int gprc_gpc_predict_latent(gprc_model* model, const double* X_star, int64_t n_star, double* fs_bar_out,
                             double* Vfs_out);
+/* GPC$predict_class (R/GPCclass.R:108-118): prob_out[i] = integral of sigmoid(z) dnorm(z, fs_bar[i], sd = Vfs[i]) dz.
+ * The latent stage is gprc_gpc_predict_latent(); the 1-D integrals (stats::integrate / QUADPACK in the reference,
+ * rel.tol 1.2e-4) run as one batched device kernel (composite Gauss-Legendre, ~1e-14).  The reference's use of the
+ * VARIANCE as dnorm's sd (:117) is reproduced.  Vfs <= 0 gives NaN. */
+GPRC_API int gprc_gpc_predict_class(gprc_model* model, const double* X_star, int64_t n_star, double* prob_out);
+/* the integral alone, for callers that already hold fs_bar / Vfs */
+GPRC_API int gprc_class_probability(gprc_ctx* ctx, const double* fs_bar, const double* Vfs, int64_t n, double* prob_out);
 GPRC_API int gprc_gpc_get_f_hat(gprc_model* model, double* f_hat_out);
 GPRC_API int gprc_gpc_get_logq(gprc_model* model, double* logq_out);
 
