@@ -322,8 +322,8 @@ int gpr_prepare(gprc_ctx* ctx, int kernel, const double* params, int n_params, c
 }
 
 int chunk_rows(const gprc_ctx* ctx, int64_t n_pad, int64_t ns) {
-  int64_t rows = ((int64_t)(ctx->chunk_bytes / (sizeof(double) * (size_t)n_pad)) - ctx->vt_pad) / 128 * 128;
-  if (rows < 128) rows = 128;
+  int64_t rows = ((int64_t)(ctx->chunk_bytes / (sizeof(double) * (size_t)n_pad)) - ctx->vt_pad) / 256 * 256;
+  if (rows < 256) rows = 256;
   const int64_t need = pad_up(ns, 128);
   return (int)(rows < need ? rows : need);
 }

@@ -329,6 +329,7 @@ static int ensure_gemm_attrs() {
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<PK_COV_SYRK>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+
   done = true;
   return 0;
 }
@@ -380,6 +381,7 @@ int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t
     by += 8.0 * (2.0 * elems + rows * NB);
   }
   ProfScope ps(s, PK_TRAILING, fl, by);
+
   hipLaunchKernelGGL(trailing_kernel, dim3((unsigned)tiles), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)p,
                      (int)q_begin, (int)q_stride, (int)nt);
   GPRC_LAUNCH_CHECK();
