@@ -100,11 +100,35 @@ _lib = None
 _lib_lock = threading.Lock()
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7) and link it by the UNVERSIONED
+    name.  If this library (linked against /opt/rocm's libamdhip64.so.7) is loaded first and torch later, the process
+    ends up with two HIP runtimes and device pointers / streams stop being interchangeable.  Loading torch's copy
+    first makes both resolve to the same object (ours by SONAME, torch's by path).  torch itself is not imported."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # torch already brought its runtime in; our NEEDED libamdhip64.so.7 matches its SONAME
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib() -> C.CDLL:
     """Load the shared library (once).  Raises ImportError with build instructions if absent."""
     global _lib
     with _lib_lock:
         if _lib is None:
+            _share_hip_runtime_with_torch()
             if not os.path.exists(LIB_PATH):
                 raise ImportError(
                     f"{LIB_PATH} not found: build it with gaussian-process-regression_amd/csrc/build.sh "

@@ -55,12 +55,19 @@ __device__ __forceinline__ double finish(double s, const KernelSpec& ks) {
   if constexpr (KID == GPRC_CONSTANT) return ks.p[0];
   else if constexpr (KID == GPRC_LINEAR) return s;
   else if constexpr (KID == GPRC_POLYNOMIAL) return r_pow(s + ks.p[0], ks.p[1]);
-  else if constexpr (KID == GPRC_SQREXP) { double l = ks.p[0]; return exp(-s / (2.0 * (l * l))); }
+  else if constexpr (KID == GPRC_SQREXP) {
+    // -s / (2 l^2): the divisor is a launch constant, so divide by reciprocal + one fma correction (the residual
+    // step of the usual division sequence) instead of the ~15-instruction generic fp64 division
+    const double c = ks.p[1], rc = ks.p[2];  // 2 l^2 and its reciprocal, precomputed on the host (make_fill_spec)
+    double q = s * rc;
+    q = fma(fma(-q, c, s), rc, q);
+    return exp(-q);
+  }
   else if constexpr (KID == GPRC_GAMMAEXP) return exp(-r_pow(sqrt(s) / ks.p[0], ks.p[1]));
   else { double l = ks.p[0], al = ks.p[1]; return r_pow(1.0 + s / (2.0 * al * (l * l)), -al); }
 }
 
-template <int KID, bool VEC2>
+template <int KID, bool VEC2, int MODE>
 __global__ __launch_bounds__(256) void fill_kernel(FillArgs a) {
   __shared__ __attribute__((aligned(16))) double As[FD][FT_R];
   __shared__ double Bs[FT_C][FD + 1];
@@ -101,16 +108,26 @@ __global__ __launch_bounds__(256) void fill_kernel(FillArgs a) {
 
   const int64_t gi0 = ti + 2 * lane;
   const int64_t row_end = a.row0 + a.nrows, col_end = a.col0 + a.ncols;
+  // interior tile: every row/column is a valid point, inside the output window, and (identity mode) off the diagonal
+  const bool interior = VEC2 && ti + FT_R <= a.nA && ti + FT_R <= row_end && tj + FT_C <= a.nB && tj + FT_C <= col_end &&
+                        (MODE != PAD_IDENTITY || ti + FT_R <= tj || tj + FT_C <= ti);
+  if (interior) {
+    double* dst = a.out + (gi0 - a.row0) + (tj + wave * 16 - a.col0) * a.ld;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      *reinterpret_cast<double2*>(dst + c * a.ld) = make_double2(finish<KID>(s0[c], a.ks), finish<KID>(s1[c], a.ks));
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
     const int64_t gj = tj + wave * 16 + c;
     if (gj >= col_end) break;
     double v0 = finish<KID>(s0[c], a.ks), v1 = finish<KID>(s1[c], a.ks);
-    if (a.mode == PAD_IDENTITY) {
+    if (MODE == PAD_IDENTITY) {
       const bool jin = gj < a.nB;
       v0 = (jin && gi0 < a.nA) ? v0 + (gi0 == gj ? a.noise : 0.0) : (gi0 == gj ? 1.0 : 0.0);
       v1 = (jin && gi0 + 1 < a.nA) ? v1 + (gi0 + 1 == gj ? a.noise : 0.0) : (gi0 + 1 == gj ? 1.0 : 0.0);
-    } else if (a.mode == PAD_ZERO) {
+    } else if (MODE == PAD_ZERO) {
       const bool jin = gj < a.nB;
       v0 = (jin && gi0 < a.nA) ? v0 : 0.0;
       v1 = (jin && gi0 + 1 < a.nA) ? v1 : 0.0;
@@ -138,14 +155,32 @@ __global__ __launch_bounds__(256) void colwise_kernel(KernelSpec ks, const doubl
   out[c] = finish<KID>(s, ks);
 }
 
-template <int KID>
-int do_fill(hipStream_t s, const FillArgs& a) {
+// device-side copy of the spec with derived constants (sqexp: p[1] = 2 l^2, p[2] = 1 / (2 l^2))
+KernelSpec make_fill_spec(const KernelSpec& ks) {
+  KernelSpec d = ks;
+  if (ks.id == GPRC_SQREXP) {
+    d.p[1] = 2.0 * (ks.p[0] * ks.p[0]);
+    d.p[2] = 1.0 / d.p[1];
+  }
+  return d;
+}
+
+template <int KID, int MODE>
+int do_fill_mode(hipStream_t s, const FillArgs& a) {
   dim3 grid((unsigned)((a.nrows + FT_R - 1) / FT_R), (unsigned)((a.ncols + FT_C - 1) / FT_C));
   const bool vec2 = (a.ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
-  if (vec2) hipLaunchKernelGGL((fill_kernel<KID, true>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((fill_kernel<KID, false>), grid, dim3(256), 0, s, a);
+  if (vec2) hipLaunchKernelGGL((fill_kernel<KID, true, MODE>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((fill_kernel<KID, false, MODE>), grid, dim3(256), 0, s, a);
   GPRC_LAUNCH_CHECK();
   return 0;
+}
+template <int KID>
+int do_fill(hipStream_t s, const FillArgs& a) {
+  switch (a.mode) {
+    case PAD_IDENTITY: return do_fill_mode<KID, PAD_IDENTITY>(s, a);
+    case PAD_ZERO: return do_fill_mode<KID, PAD_ZERO>(s, a);
+    default: return do_fill_mode<KID, PAD_NONE>(s, a);
+  }
 }
 
 }  // namespace
@@ -155,7 +190,7 @@ int launch_fill(hipStream_t s, const KernelSpec& ks, const double* A, int64_t nA
                 double noise) {
   if (nrows <= 0 || ncols <= 0) return 0;
   if ((ncols + FT_C - 1) / FT_C > 65535) { set_error("fill: too many column tiles in one launch"); return GPRC_ERR_ARG; }
-  FillArgs a{A, B, out, nA, nB, d, ld, row0, nrows, col0, ncols, (int)mode, noise, ks};
+  FillArgs a{A, B, out, nA, nB, d, ld, row0, nrows, col0, ncols, (int)mode, noise, make_fill_spec(ks)};
   ProfScope ps(s, PK_FILL, (double)nrows * ncols * (3.0 * d + 20.0), 8.0 * nrows * ncols);
   switch (ks.id) {
     case GPRC_CONSTANT: return do_fill<GPRC_CONSTANT>(s, a);
@@ -171,13 +206,14 @@ int launch_fill(hipStream_t s, const KernelSpec& ks, const double* A, int64_t nA
 int launch_colwise(hipStream_t s, const KernelSpec& ks, const double* x, const double* y, int64_t d, int64_t m, double* out) {
   if (m <= 0) return 0;
   dim3 grid((unsigned)((m + 255) / 256));
+  const KernelSpec ksd = make_fill_spec(ks);
   switch (ks.id) {
-    case GPRC_CONSTANT: hipLaunchKernelGGL((colwise_kernel<GPRC_CONSTANT>), grid, dim3(256), 0, s, ks, x, y, d, m, out); break;
-    case GPRC_LINEAR: hipLaunchKernelGGL((colwise_kernel<GPRC_LINEAR>), grid, dim3(256), 0, s, ks, x, y, d, m, out); break;
-    case GPRC_POLYNOMIAL: hipLaunchKernelGGL((colwise_kernel<GPRC_POLYNOMIAL>), grid, dim3(256), 0, s, ks, x, y, d, m, out); break;
-    case GPRC_SQREXP: hipLaunchKernelGGL((colwise_kernel<GPRC_SQREXP>), grid, dim3(256), 0, s, ks, x, y, d, m, out); break;
-    case GPRC_GAMMAEXP: hipLaunchKernelGGL((colwise_kernel<GPRC_GAMMAEXP>), grid, dim3(256), 0, s, ks, x, y, d, m, out); break;
-    case GPRC_RATQUAD: hipLaunchKernelGGL((colwise_kernel<GPRC_RATQUAD>), grid, dim3(256), 0, s, ks, x, y, d, m, out); break;
+    case GPRC_CONSTANT: hipLaunchKernelGGL((colwise_kernel<GPRC_CONSTANT>), grid, dim3(256), 0, s, ksd, x, y, d, m, out); break;
+    case GPRC_LINEAR: hipLaunchKernelGGL((colwise_kernel<GPRC_LINEAR>), grid, dim3(256), 0, s, ksd, x, y, d, m, out); break;
+    case GPRC_POLYNOMIAL: hipLaunchKernelGGL((colwise_kernel<GPRC_POLYNOMIAL>), grid, dim3(256), 0, s, ksd, x, y, d, m, out); break;
+    case GPRC_SQREXP: hipLaunchKernelGGL((colwise_kernel<GPRC_SQREXP>), grid, dim3(256), 0, s, ksd, x, y, d, m, out); break;
+    case GPRC_GAMMAEXP: hipLaunchKernelGGL((colwise_kernel<GPRC_GAMMAEXP>), grid, dim3(256), 0, s, ksd, x, y, d, m, out); break;
+    case GPRC_RATQUAD: hipLaunchKernelGGL((colwise_kernel<GPRC_RATQUAD>), grid, dim3(256), 0, s, ksd, x, y, d, m, out); break;
     default: set_error("unknown kernel id"); return GPRC_ERR_ARG;
   }
   GPRC_LAUNCH_CHECK();
