@@ -408,15 +408,26 @@ int gprc_kernel_matrix(gprc_ctx* ctx, int kernel, const double* params, int n_pa
   GPRC_TRY(make_spec(kernel, params, n_params, d, &ks));
   hipStream_t s = ctx->stream;
   In a, b;
-  Out o;
   GPRC_TRY(a.set(s, A, d * nA));
   GPRC_TRY(b.set(s, B, d * nB));
-  GPRC_TRY(o.set(out, ld_out * nB));
+  // device output: written in place with the caller's leading dimension; host output: a compact nA x nB staging
+  // matrix copied back with the caller's pitch, so rows nA..ld_out-1 of the caller's array are never touched
+  const bool dev_out = is_device_ptr(out);
+  DevMem stage;
+  double* dst = out;
+  int64_t ld = ld_out;
+  if (!dev_out) {
+    GPRC_TRY(stage.alloc(nA * nB));
+    dst = stage.p;
+    ld = nA;
+  }
   for (int64_t c0 = 0; c0 < nB; c0 += 1 << 20) {  // grid.y limit
     const int64_t nc = (nB - c0 < (1 << 20)) ? nB - c0 : (1 << 20);
-    GPRC_TRY(launch_fill(s, ks, a.dev, nA, b.dev, nB, d, o.dev + c0 * ld_out, ld_out, 0, nA, c0, nc, PAD_NONE, 0.0));
+    GPRC_TRY(launch_fill(s, ks, a.dev, nA, b.dev, nB, d, dst + c0 * ld, ld, 0, nA, c0, nc, PAD_NONE, 0.0));
   }
-  GPRC_TRY(o.finish(s));
+  if (!dev_out)
+    GPRC_HIP(hipMemcpy2DAsync(out, sizeof(double) * ld_out, stage.p, sizeof(double) * nA, sizeof(double) * nA, nB,
+                              hipMemcpyDeviceToHost, s));
   GPRC_HIP(hipStreamSynchronize(s));
   return 0;
 }
@@ -548,11 +559,18 @@ int gprc_model_get_L(gprc_model* m, double* L_out, int64_t ld_out) {
   if (!m || !L_out || ld_out < m->n) { set_error("get_L: bad arguments"); return GPRC_ERR_ARG; }
   GPRC_TRY(use_device(m->ctx));
   hipStream_t s = m->ctx->stream;
-  Out o;
-  GPRC_TRY(o.set(L_out, ld_out * m->n));
-  if (o.host && ld_out != m->n) GPRC_HIP(hipMemsetAsync(o.dev, 0, sizeof(double) * ld_out * m->n, s));
-  GPRC_TRY(launch_unpack_L(s, m->packed, m->n_pad, m->n, o.dev, ld_out));
-  GPRC_TRY(o.finish(s));
+  const int64_t n = m->n;
+  if (is_device_ptr(L_out)) {
+    GPRC_TRY(launch_unpack_L(s, m->packed, m->n_pad, n, L_out, ld_out));
+  } else {  // compact staging + pitched copy: only the n x n block of the caller's array is written
+    DevMem stage;
+    GPRC_TRY(stage.alloc(n * n));
+    GPRC_TRY(launch_unpack_L(s, m->packed, m->n_pad, n, stage.p, n));
+    GPRC_HIP(hipMemcpy2DAsync(L_out, sizeof(double) * ld_out, stage.p, sizeof(double) * n, sizeof(double) * n, n,
+                              hipMemcpyDeviceToHost, s));
+    GPRC_HIP(hipStreamSynchronize(s));
+    return 0;
+  }
   GPRC_HIP(hipStreamSynchronize(s));
   return 0;
 }

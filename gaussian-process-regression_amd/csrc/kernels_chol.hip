@@ -36,23 +36,26 @@ constexpr int PB = 128;
 // (c > i) are updated harmlessly and never read, and row scaling is deferred to the final store.
 // Only the pivot column (owners: ty == j % 8) and row j of Y (owners: i == j) cross threads, through a
 // double-buffered LDS line: ONE barrier per column.  Scaling multiplies by 1/l_jj as LAPACK dpotf2 does.
-__global__ __launch_bounds__(1024) void potf2_inv_kernel(double* A, int64_t lda, double* winv, int* info, int col0) {
+// TY = number of column groups: TY * 128 threads, E = 128 / TY elements per thread (c = ty + TY * k).
+template <int TY>
+__global__ __launch_bounds__(TY * 128) void potf2_inv_kernel(double* A, int64_t lda, double* winv, int* info, int col0) {
+  constexpr int E = PB / TY;
   __shared__ double pub[2][PB + 2];  // [PB] = l_jj, [PB+1] = 1/l_jj, computed once by the pivot's owner
   const int t = threadIdx.x;
   const int i = t & 127, ty = t >> 7;
   const int wave_last_row = (t & 64) + 63;   // rows of this wave: (t & 64) .. +63
-  double reg[16];
+  double reg[E];
   double my_rinv = 1.0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int c = ty + 8 * k;
+  for (int k = 0; k < E; ++k) {
+    const int c = ty + TY * k;
     reg[k] = (c <= i) ? A[i + (int64_t)c * lda] : 0.0;
   }
 #pragma unroll
-  for (int kb = 0; kb < 16; ++kb) {     // compile-time register index of the pivot column: reg[kb]
+  for (int kb = 0; kb < E; ++kb) {     // compile-time register index of the pivot column: reg[kb]
 #pragma unroll 1
-    for (int jj = 0; jj < 8; ++jj) {
-      const int j = kb * 8 + jj;
+    for (int jj = 0; jj < TY; ++jj) {
+      const int j = kb * TY + jj;
       double* line = pub[j & 1];
       // publish: pivot column A[.][j] (rows >= j) by its owners, row j of Y (cols < j) by row j
       if (ty == jj && i >= j) line[i] = reg[kb];
@@ -63,8 +66,8 @@ __global__ __launch_bounds__(1024) void potf2_inv_kernel(double* A, int64_t lda,
           line[PB + 1] = 1.0 / l;
         }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const int c = ty + 8 * k;
+        for (int k = 0; k < E; ++k) {
+          const int c = ty + TY * k;
           if (c < j) line[c] = reg[k];
         }
       }
@@ -78,17 +81,17 @@ __global__ __launch_bounds__(1024) void potf2_inv_kernel(double* A, int64_t lda,
       const double lij = below ? line[i] * rinv : 0.0;
       const double mult = -lij * rinv;   // -(L[i][j] / l_jj): one fma per element against the UNSCALED line
       if (wave_last_row >= 64) {
-        double lv[16];
+        double lv[E];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) lv[k] = line[ty + 8 * k];
+        for (int k = 0; k < E; ++k) lv[k] = line[ty + TY * k];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) reg[k] = fma(mult, lv[k], reg[k]);
-      } else {                           // rows 0..63: columns c = ty + 8k > 63 are all above the diagonal
-        double lv[8];
+        for (int k = 0; k < E; ++k) reg[k] = fma(mult, lv[k], reg[k]);
+      } else {                           // rows 0..63: columns c > 63 are all above the diagonal
+        double lv[E / 2];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) lv[k] = line[ty + 8 * k];
+        for (int k = 0; k < E / 2; ++k) lv[k] = line[ty + TY * k];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) reg[k] = fma(mult, lv[k], reg[k]);
+        for (int k = 0; k < E / 2; ++k) reg[k] = fma(mult, lv[k], reg[k]);
       }
       if (ty == jj) {                    // the pivot column itself: final L[i][j], first inverse entry
         if (below) { A[i + (int64_t)j * lda] = lij; reg[kb] = mult; }
@@ -99,8 +102,8 @@ __global__ __launch_bounds__(1024) void potf2_inv_kernel(double* A, int64_t lda,
   }
   // Winv = L^-1 = diag(1/l_ii) * Y, dense 128 x 128 column-major, zero above the diagonal
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int c = ty + 8 * k;
+  for (int k = 0; k < E; ++k) {
+    const int c = ty + TY * k;
     winv[i + c * PB] = (c <= i) ? reg[k] * my_rinv : 0.0;
   }
 }
@@ -311,7 +314,8 @@ __global__ __launch_bounds__(256, 2) void trailing_kernel(double* packed, int64_
 
 int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* info_dev, int col0) {
   ProfScope ps(s, PK_POTF2, 128.0 * 128 * 128 / 3 * 2, 8.0 * 3 * 128 * 128);
-  hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(1024), 0, s, A, lda, winv, info_dev, col0);
+  // 8 column groups x 128 rows = 1024 threads; 4 and 2 groups (fatter threads) measured 6x and 9x slower
+  hipLaunchKernelGGL(potf2_inv_kernel<8>, dim3(1), dim3(1024), 0, s, A, lda, winv, info_dev, col0);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,81 @@
+/* Plain-C consumer of include/gprc_native.h -- what the R `.Call` shim does, minus R: host arrays in, host arrays
+ * out, status codes, opaque handles.  Runs the reference's closed-form case (tests/testthat/test-gpr.R:23-27), the
+ * jitter loop on a robustly indefinite input, a GPC fit + class probabilities, and the error paths.
+ * Built and run by tests/test_gpu_c_abi.py (gcc, links libgprc_native.so only).  Exit code 0 = all checks passed. */
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gprc_native.h"
+
+static int fails = 0;
+#define CHECK(cond, ...)                                  \
+  do {                                                    \
+    if (!(cond)) { printf("FAIL %s:%d ", __FILE__, __LINE__); printf(__VA_ARGS__); printf("\n"); ++fails; } \
+  } while (0)
+
+int main(void) {
+  gprc_ctx* ctx = NULL;
+  int ndev = 0;
+  CHECK(gprc_abi_version() == GPRC_ABI_VERSION, "abi version");
+  CHECK(gprc_device_count(&ndev) == 0 && ndev >= 1, "device count %d", ndev);
+  int rc = gprc_ctx_create(0, NULL, &ctx);
+  CHECK(rc == 0, "ctx_create rc=%d (%s)", rc, gprc_last_error());
+  if (rc != 0) return 2;
+
+  /* GPR.sqrexp$new(X = (1,2), y = (0,1), noise = 1, l = 1)$predict(0) */
+  const double X[2] = {1.0, 2.0}, y[2] = {0.0, 1.0}, l = 1.0, xs = 0.0;
+  gprc_model* m = NULL;
+  double noise_used = -1.0, mean = 0.0, var = 0.0, alpha[2], logp = 0.0, L[4];
+  int attempts = 0;
+  rc = gprc_gpr_fit_retry(ctx, GPRC_SQREXP, &l, 1, X, 1, 2, y, 1.0, &m, &noise_used, &attempts);
+  CHECK(rc == 0 && attempts == 1 && noise_used == 1.0, "fit_retry rc=%d attempts=%d noise=%g", rc, attempts, noise_used);
+  CHECK(gprc_gpr_predict(m, &xs, 1, 1, &mean, &var) == 0, "predict");
+  const double em = (2 * exp(-2.0) - exp(-1.0)) / (4 - exp(-1.0));
+  const double ev = 1 - (2 * exp(-1.0) - 2 * exp(-3.0) + 2 * exp(-4.0)) / (4 - exp(-1.0));
+  CHECK(fabs(mean - em) < 1e-15 && fabs(var - ev) < 1e-15, "known answer: mean %.17g var %.17g", mean, var);
+  CHECK(gprc_gpr_get_alpha(m, alpha) == 0 && gprc_gpr_get_logp(m, &logp) == 0 && gprc_model_get_L(m, L, 2) == 0, "getters");
+  CHECK(fabs(L[0] - sqrt(2.0)) < 1e-15 && L[2] == 0.0 && fabs(L[1] - exp(-0.5) / sqrt(2.0)) < 1e-15, "L = t(chol(K + I))");
+  int64_t n = 0, d = 0;
+  CHECK(gprc_model_dims(m, &n, &d) == 0 && n == 2 && d == 1, "dims");
+  gprc_model_free(m);
+
+  /* one attempt on an indefinite matrix -> LAPACK info; the jitter loop recovers at the 4th attempt */
+  const double Xn[2] = {0.15, 0.05}, yn[2] = {1.0, -1.0}, sigma = -1.0;
+  m = NULL;
+  rc = gprc_gpr_fit(ctx, GPRC_LINEAR, &sigma, 1, Xn, 1, 2, yn, 0.0, &m);
+  CHECK(rc == 1 && m == NULL && strstr(gprc_last_error(), "leading minor of order 1") != NULL, "info rc=%d msg=%s", rc, gprc_last_error());
+  rc = gprc_gpr_fit_retry(ctx, GPRC_LINEAR, &sigma, 1, Xn, 1, 2, yn, 0.0, &m, &noise_used, &attempts);
+  CHECK(rc == 0 && attempts == 4 && noise_used == 0.03, "jitter rc=%d attempts=%d noise=%.17g", rc, attempts, noise_used);
+  gprc_model_free(m);
+  const double Xp[3] = {2.0, 0.1, 0.5}, yp[3] = {1, 2, 3}, pp[2] = {-1.0, 1.0};
+  m = NULL;
+  rc = gprc_gpr_fit_retry(ctx, GPRC_POLYNOMIAL, pp, 2, Xp, 1, 3, yp, 0.0, &m, &noise_used, &attempts);
+  CHECK(rc == GPRC_ERR_NOT_PD && m == NULL, "all ten attempts fail rc=%d", rc);
+
+  /* argument errors never abort */
+  CHECK(gprc_gpr_fit(ctx, 99, &l, 1, X, 1, 2, y, 1.0, &m) == GPRC_ERR_ARG, "unknown kernel id");
+  CHECK(gprc_gpr_fit(ctx, GPRC_SQREXP, &l, 2, X, 1, 2, y, 1.0, &m) == GPRC_ERR_ARG, "wrong parameter count");
+  CHECK(gprc_gpr_fit(ctx, GPRC_SQREXP, &l, 1, X, 1, 2, y, -1.0, &m) == GPRC_ERR_ARG, "negative noise");
+
+  /* GPC: 1-D step problem of tests/testthat/test-gpc.R:5-10 (kappa = exp(-3 (x-y)^2) -> sqrexp, l = sqrt(1/6)) */
+  double Xc[21], yc[21], probe[2] = {-0.2, 0.2}, prob[2], lc = sqrt(1.0 / 6.0);
+  for (int i = 0; i < 21; ++i) { Xc[i] = -1.0 + 0.1 * i; yc[i] = Xc[i] > 1e-12 ? 1.0 : -1.0; }
+  int iters = 0;
+  m = NULL;
+  rc = gprc_gpc_fit(ctx, GPRC_SQREXP, &lc, 1, Xc, 1, 21, yc, 1e-5, 0, GPRC_GPC_REFERENCE_STOP, &m, &iters);
+  CHECK(rc == 0 && iters >= 2 && iters < 30, "gpc_fit rc=%d iters=%d", rc, iters);
+  CHECK(gprc_gpc_predict_class(m, probe, 2, prob) == 0 && prob[0] < 0.5 && prob[1] > 0.5, "gpc probs %g %g", prob[0], prob[1]);
+  gprc_model_free(m);
+
+  /* covariance_matrix with an odd leading dimension */
+  const double A[6] = {0, 0, 1, 0, 0, 1};  /* three 2-d points */
+  double K[3 * 5];
+  for (int i = 0; i < 15; ++i) K[i] = -7.0;
+  CHECK(gprc_kernel_matrix(ctx, GPRC_SQREXP, &l, 1, A, 2, 3, A, 3, K, 5) == 0, "kernel_matrix");
+  CHECK(K[0] == 1.0 && fabs(K[1] - exp(-0.5)) < 1e-16 && fabs(K[5 + 2] - exp(-1.0)) < 1e-16 && K[3] == -7.0, "kernel_matrix values / ld");
+
+  gprc_ctx_destroy(ctx);
+  printf(fails ? "c_abi_client: %d FAILED\n" : "c_abi_client: all checks passed\n", fails);
+  return fails ? 1 : 0;
+}
