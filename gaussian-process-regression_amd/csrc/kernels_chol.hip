@@ -11,6 +11,8 @@
 //                     trailing update over the packed block-column layout (lower tiles only).
 // The trailing update is the dominant kernel of the whole path: n^3/3 of the fit and n^2 n* of the
 // predict go through gemm_tile_128().
+#include <cstdlib>
+
 #include "gprc_internal.h"
 
 namespace gprc {
@@ -105,6 +107,183 @@ __global__ __launch_bounds__(TY * 128) void potf2_inv_kernel(double* A, int64_t 
   for (int k = 0; k < E; ++k) {
     const int c = ty + TY * k;
     winv[i + c * PB] = (c <= i) ? reg[k] * my_rinv : 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Blocked diagonal-block kernel (default): the same factor + inverse, 16 columns at a time.
+// The 128 x 128 block lives in LDS (leading dimension 144: MFMA operand reads conflict-free).  Per 16-column step:
+//   A  wave 0 factors the 16 x 16 diagonal sub-block and inverts it with the register-resident scalar sweep above
+//      (16 sequential pivots; sqrt / reciprocal from a Newton-refined v_rsq_f64 -- ~100 dependent cycles instead of
+//      the ~600 of the library sqrt + division);
+//   B  panel rows below: X_I = A_I * Wd^T, and row s of the inverse: X_sJ = Wd * Y_sJ   (4 MFMAs per 16x16 block);
+//   C  Cholesky trailing blocks C_IJ -= X_I X_J^T and inverse blocks Y_IJ -= L_Is X_sJ  (4 MFMAs per block),
+// one barrier after each phase.  L is kept in the lower triangle, the (unscaled-free) inverse transposed in the
+// upper triangle, its diagonal in a side array -- the layout of the output.  The sequential depth drops from 128
+// whole-workgroup steps to 128 single-wave steps on 16-row data.
+// ------------------------------------------------------------------------------------------------
+constexpr int BLD = 144;
+constexpr int PB_SMEM_DOUBLES = PB * BLD + 256 + PB + 2 * 20;  // S, Wd, Wdiag, 2 publish lines
+
+// sqrt(d) and 1/sqrt(d) from v_rsq_f64 + two Newton steps (+ one correction of the root)
+__device__ __forceinline__ void sqrt_rsqrt(double d, double& root, double& rinv) {
+  double r = __builtin_amdgcn_rsq(d);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double e = fma(-(d * r), r, 1.0);  // 1 - d r^2
+    r = fma(0.5 * r, e, r);
+  }
+  double l = d * r;
+  l = fma(0.5 * r, fma(-l, l, d), l);
+  root = l;
+  rinv = r;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Phase A: one wave (64 lanes) factors the 16x16 block at D (LDS, ld BLD) in place (lower), writes its inverse
+// dense to Wd[16][16] (column-major), transposed-strict-lower into D's upper triangle and the diagonal to wdiag.
+__device__ __forceinline__ void diag16(double* D, double* Wd, double* wdiag, double* lines, int* info, int col) {
+  const int l = threadIdx.x & 63, i = l & 15, ty = l >> 4;
+  double reg[4];
+  double my_rinv = 1.0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = ty + 4 * k;
+    reg[k] = (c <= i) ? D[i + c * BLD] : 0.0;
+  }
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = kb * 4 + jj;
+      double* line = lines + (j & 1) * 20;
+      if (ty == jj && i >= j) line[i] = reg[kb];
+      if (i == j) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = ty + 4 * k;
+          if (c < j) line[c] = reg[k];
+        }
+      }
+      wave_lds_sync();
+      const double d = line[j];
+      if (!(d > 0.0) && l == 0) atomicCAS(info, 0, col + j + 1);  // LAPACK info: first non-PD leading minor
+      double ljj, rinv;
+      sqrt_rsqrt(d, ljj, rinv);
+      const bool below = i > j;
+      const double lij = below ? line[i] * rinv : 0.0;
+      const double mult = -lij * rinv;
+      double lv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) lv[k] = line[ty + 4 * k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) reg[k] = fma(mult, lv[k], reg[k]);
+      if (ty == jj) {
+        if (below) { D[i + j * BLD] = lij; reg[kb] = mult; }
+        else if (i == j) { D[j + j * BLD] = ljj; reg[kb] = 1.0; }
+      }
+      if (i == j) my_rinv = rinv;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = ty + 4 * k;
+    const double w = (c <= i) ? reg[k] * my_rinv : 0.0;
+    Wd[i + c * 16] = w;
+    if (c < i) D[c + i * BLD] = w;  // strict lower part of the inverse, transposed into the upper triangle
+    if (c == i) wdiag[i] = w;
+  }
+}
+
+// 16x16x16 block product on one wave: acc (+/-)= Aop * Bop with Aop[x][k] = pa[x + k*lda_], Bop[k][y] = pb[y + k*ldb_]
+// (both operands are addressed "row index contiguous"), acc lane layout D[x = (lane>>4) + 4r][y = lane&15].
+template <int NEG>
+__device__ __forceinline__ double4_t block_mma(const double* pa, int lda_, const double* pb, int ldb_, double4_t acc) {
+  const int l = threadIdx.x & 63, q = l >> 4, r = l & 15;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[r + (4 * kk + q) * lda_], pb[r + (4 * kk + q) * ldb_], acc, 0, 0, NEG);
+  return acc;
+}
+
+__global__ __launch_bounds__(1024) void potf2_inv_blocked_kernel(double* A, int64_t lda, double* winv, int* info, int col0) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* S = sm;                      // PB x BLD
+  double* Wd = sm + PB * BLD;          // 16 x 16
+  double* Wdiag = Wd + 256;            // PB
+  double* lines = Wdiag + PB;          // 2 x 20
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int q = lane >> 4, r = lane & 15;
+  {
+    const int i = t & 127, ty = t >> 7;
+    for (int c = ty; c < PB; c += 8) S[i + c * BLD] = (i >= c) ? A[i + (int64_t)c * lda] : 0.0;
+  }
+  __syncthreads();
+  for (int s = 0; s < 8; ++s) {
+    const int c0 = 16 * s, m = 7 - s;
+    if (wave == 0) diag16(S + c0 + c0 * BLD, Wd, Wdiag + c0, lines, info, col0 + c0);
+    __syncthreads();
+    // ---- phase B: panel below (waves 0..m-1), inverse row s (waves 8..8+s-1)
+    if (wave < m) {
+      const int I = s + 1 + wave;
+      // D'[x][y] = sum_k Wd[x][k] * A_I[y][k] = X_I[y][x]
+      double4_t acc = block_mma<0>(Wd, 16, S + 16 * I + c0 * BLD, BLD, (double4_t){0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) S[(16 * I + r) + (c0 + q + 4 * rr) * BLD] = acc[rr];
+    } else if (wave >= 8 && wave - 8 < s) {
+      const int J = wave - 8;
+      // X_sJ[a][b] = sum_k Wd[a][k] * Y_sJ[k][b]; Y_sJ[k][b] sits transposed at S[(16J + b) + (c0 + k) * BLD]
+      double4_t acc = block_mma<0>(Wd, 16, S + 16 * J + c0 * BLD, BLD, (double4_t){0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) S[(16 * J + r) + (c0 + q + 4 * rr) * BLD] = acc[rr];
+    }
+    __syncthreads();
+    // ---- phase C: m(m+1)/2 Cholesky blocks then m*(s+1) inverse blocks, round-robin over the 16 waves
+    const int nchol = m * (m + 1) / 2, ninv = m * (s + 1);
+    for (int b = wave; b < nchol + ninv; b += 16) {
+      if (b < nchol) {
+        int ii = 0;
+        while ((ii + 1) * (ii + 2) / 2 <= b) ++ii;
+        const int I = s + 1 + ii, J = s + 1 + (b - ii * (ii + 1) / 2);
+        // D'[x][y] = C_IJ[y][x]: lanes run down the rows of C_IJ (contiguous in LDS)
+        double4_t acc;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[rr] = S[(16 * I + r) + (16 * J + q + 4 * rr) * BLD];
+        acc = block_mma<1>(S + 16 * J + c0 * BLD, BLD, S + 16 * I + c0 * BLD, BLD, acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) S[(16 * I + r) + (16 * J + q + 4 * rr) * BLD] = acc[rr];
+      } else {
+        const int e = b - nchol;
+        const int I = s + 1 + e / (s + 1), J = e % (s + 1);
+        // Y_IJ[a][b'] -= sum_k L_Is[a][k] * X_sJ[k][b'];  Y_IJ[a][b'] sits transposed at S[(16J + b') + (16I + a) * BLD]
+        double4_t acc;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[rr] = S[(16 * J + r) + (16 * I + q + 4 * rr) * BLD];
+        if (J < s) acc = block_mma<1>(S + 16 * I + c0 * BLD, BLD, S + 16 * J + c0 * BLD, BLD, acc);
+        else {  // X_ss = Wd: Bop[k][b'] = Wd[k][b'] = Wd[k + b' * 16]  -> "row index contiguous" means pb[b' + k * ld] with the transposed view
+          const int l = lane;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(16 * I + (l & 15)) + (c0 + 4 * kk + (l >> 4)) * BLD],
+                                                       Wd[(4 * kk + (l >> 4)) + (l & 15) * 16], acc, 0, 0, 1);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) S[(16 * J + r) + (16 * I + q + 4 * rr) * BLD] = acc[rr];
+      }
+    }
+    __syncthreads();
+  }
+  {
+    const int i = t & 127, ty = t >> 7;
+    for (int c = ty; c < PB; c += 8) {
+      if (i >= c) A[i + (int64_t)c * lda] = S[i + c * BLD];
+      winv[i + c * PB] = (i > c) ? S[c + i * BLD] : (i == c ? Wdiag[i] : 0.0);
+    }
   }
 }
 
@@ -314,8 +493,19 @@ __global__ __launch_bounds__(256, 2) void trailing_kernel(double* packed, int64_
 
 int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* info_dev, int col0) {
   ProfScope ps(s, PK_POTF2, 128.0 * 128 * 128 / 3 * 2, 8.0 * 3 * 128 * 128);
-  // 8 column groups x 128 rows = 1024 threads; 4 and 2 groups (fatter threads) measured 6x and 9x slower
-  hipLaunchKernelGGL(potf2_inv_kernel<8>, dim3(1), dim3(1024), 0, s, A, lda, winv, info_dev, col0);
+  static const bool scalar = std::getenv("GPRC_POTF2_SCALAR") != nullptr;  // the unblocked register-resident kernel
+  if (scalar) {
+    // 8 column groups x 128 rows = 1024 threads; 4 and 2 groups (fatter threads) measured 6x and 9x slower
+    hipLaunchKernelGGL(potf2_inv_kernel<8>, dim3(1), dim3(1024), 0, s, A, lda, winv, info_dev, col0);
+  } else {
+    static bool attr_set = false;
+    const size_t smem = PB_SMEM_DOUBLES * sizeof(double);
+    if (!attr_set) {
+      GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_blocked_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(potf2_inv_blocked_kernel, dim3(1), dim3(1024), smem, s, A, lda, winv, info_dev, col0);
+  }
   GPRC_LAUNCH_CHECK();
   return 0;
 }
