@@ -57,6 +57,7 @@ PROTOTYPES = {
     "gprc_gpr_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, C.c_double, C.POINTER(_vp)]),
     "gprc_gpr_fit_retry": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, C.c_double, C.POINTER(_vp),
                                      C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "gprc_gpr_log_marginal": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, C.c_double, C.POINTER(C.c_double)]),
     "gprc_gpr_predict": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
     "gprc_model_dims": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "gprc_model_get_L": (C.c_int, [_vp, _vp, _i64]),

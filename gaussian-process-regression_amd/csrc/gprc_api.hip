@@ -467,6 +467,20 @@ int gprc_gpr_fit(gprc_ctx* ctx, int kernel, const double* params, int n_params, 
   return 0;
 }
 
+int gprc_gpr_log_marginal(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d,
+                          int64_t n, const double* y, double noise, double* logp_out) {
+  if (!logp_out) { set_error("log_marginal: null output"); return GPRC_ERR_ARG; }
+  gprc_model* m = nullptr;
+  GPRC_TRY(gpr_prepare(ctx, kernel, params, n_params, X, d, n, y, noise, &m));
+  int info = 0;
+  const int rc = gpr_attempt(m, noise, &info);
+  if (rc == 0 && info == 0) *logp_out = m->logp;
+  free_model(m);
+  if (rc != 0) return rc;
+  if (info != 0) { set_error("the leading minor of order " + std::to_string(info) + " is not positive definite"); return info; }
+  return 0;
+}
+
 int gprc_gpr_fit_retry(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d,
                        int64_t n, const double* y, double noise, gprc_model** model_out, double* noise_used,
                        int* attempts) {

@@ -46,10 +46,10 @@ class GPR:
 
     def __init__(self, X, y, noise=0, k=None, cov_names=None, *, ctx=None):
         if k is None:
-            # the reference default is k = fit(X, y, noise, cov_names)$func (R/GPRclass.R:127); fit() is the
-            # first "next" row of the scope table and is not on this hot path yet.
-            raise NotImplementedError("GPR: pass k = cov_func(...); the default k = fit(...)$func is not part of the "
-                                      "MI355X hot path yet")
+            # the reference default: k = fit(X, y, noise, cov_names)$func (R/GPRclass.R:127).  fit() here covers the
+            # Brent-optimised kernels; with the full default list it raises NotImplementedError for the BFGS ones.
+            from .fit import fit as _fit
+            k = _fit(X, y, noise, cov_names, ctx=ctx)["func"]
         Xa = np.asarray(X)
         if Xa.dtype.kind not in "fiub" or not _is_numeric_vector(y):
             raise TypeError("is.numeric(X), is.vector(y), is.numeric(y) are not all TRUE")   # :129

@@ -101,6 +101,12 @@ GPRC_API int gprc_gpr_fit(gprc_ctx* ctx, int kernel, const double* params, int n
 GPRC_API int gprc_gpr_fit_retry(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d,
                        int64_t n, const double* y, double noise, gprc_model** model_out, double* noise_used,
                        int* attempts);
+/* dens(v), the objective of fit() (R/fit.R:117-124): the log marginal likelihood of (kernel, params) on (X, y, noise),
+ * i.e. kernel fill + Cholesky + alpha + logp without keeping a model.  Returns 0 and *logp_out, or info > 0 when
+ * K + noise*I is not positive definite.  The reference guards with min(det(leading minors)) > 0 (:119, O(n^4));
+ * the Cholesky's own info is the same test in exact arithmetic. */
+GPRC_API int gprc_gpr_log_marginal(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d,
+                          int64_t n, const double* y, double noise, double* logp_out);
 /* GPR$predict (R/GPRclass.R:155-170).  X_star is d x n_star.
  * pointwise != 0: mean_out[n_star], var_out[n_star] = k(x*,x*) - colSums(v*v)      (:164-165)
  * pointwise == 0: mean_out[n_star], var_out = n_star x n_star K(X*,X*) - t(v) %*% v (:167-168) */

@@ -130,3 +130,29 @@ def test_compute_fails_loudly_without_gpu():
         covariance_matrix(np.zeros((1, 3)), np.zeros((1, 3)), k)
     with pytest.raises(GprcError):
         k(np.zeros((1, 3)), np.zeros((1, 3)))
+
+
+def test_brent_fmin_restatement_against_scipy():
+    """R's optim(method = "Brent") is Brent's fmin; the restatement in gprc_amd.fit must find the same minima as
+    scipy's independent implementation of the same published algorithm."""
+    import math
+    from scipy.optimize import minimize_scalar
+    from gprc_amd.fit import brent_fmin
+    tol = math.sqrt(np.finfo(float).eps)
+    cases = [(lambda x: (x - 2.3) ** 2 + 1, 0, 10), (lambda x: math.cos(x) + 0.1 * x, 0, 10), (lambda x: -x * math.exp(-x), 0, 5),
+             (lambda x: abs(x - 7.123) ** 1.5, 0, 10), (lambda x: -1.0 / (1 + (x - 0.4) ** 2), 0, 10)]
+    for f, a, b in cases:
+        mine = brent_fmin(f, a, b, tol)
+        ref = minimize_scalar(f, bounds=(a, b), method="bounded", options={"xatol": 1e-10}).x
+        assert abs(mine - ref) <= 2e-6 * max(1.0, abs(ref)), (mine, ref)
+    calls = []
+    brent_fmin(lambda x: calls.append(x) or (x - 1) ** 2, 0, 10, tol)
+    assert abs(calls[0] - (0 + (3 - math.sqrt(5)) / 2 * 10)) < 1e-15      # first probe: the golden-section point
+
+
+def test_fit_rejects_bfgs_kernels_loudly():
+    from gprc_amd import fit
+    with pytest.raises(NotImplementedError, match="BFGS"):
+        fit(np.zeros((1, 4)), np.zeros(4), 0.1)                            # default list includes gammaexp / rationalquadratic
+    with pytest.raises(NotImplementedError):
+        fit(np.zeros((1, 4)), np.zeros(4), 0.1, ["sqrexp", "rationalquadratic"])
