@@ -104,3 +104,24 @@ def test_gpc_config5_size_stationarity():
     fs, vf = gc.predict_latent(X[:, :1000])
     assert np.all(np.sign(fs) == y[:1000]) or (np.sign(fs) == y[:1000]).mean() > 0.97   # training points mostly reclassified
     assert (vf > 0).all() and (vf <= 1.0 + 1e-12).all()
+
+
+def test_config4_size_identities():
+    """BASELINE config 4 size on ONE GPU (n = 65536, d = 8, sqexp; 128 panels, 17 GB factor), where no CPU check is
+    affordable: size-independent identities of the posterior.  (a) K alpha = y - noise * alpha, read off the posterior
+    mean at training inputs (exercises every panel of the factor through both triangular solves, the K*^T fill and the
+    GEMV); (b) at a training input 0 < var < noise; (c) chunk invariance: a different chunking gives identical bits;
+    (d) sanity bounds on alpha."""
+    n, d, noise = 65536, 8, 0.1
+    X, y, _ = _inputs(n, d, 8)
+    g = GPR(X, y, noise, cov_func(sqrexp, l=1.0))
+    idx = np.r_[0:512, 30000:30512, n - 512:n]              # first, middle and last panels' points
+    pr = g.predict(X[:, idx])
+    assert nerr(pr[:, 0], (y - noise * g.alpha)[idx]) <= 1e-9
+    assert (pr[:, 1] > 0).all() and (pr[:, 1] < noise).all()
+    pr2 = np.vstack([g.predict(X[:, idx[:700]]), g.predict(X[:, idx[700:]])])
+    assert np.array_equal(pr, pr2)
+    assert np.isfinite(g.logp)   # (a log-density: its sign is not constrained)
+    # y . alpha > 0 for an SPD system, and |alpha| bounded by |y| / noise
+    assert float(y @ g.alpha) > 0 and np.abs(g.alpha).max() <= np.abs(y).max() / noise * 1.0001
+    g.close()
