@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
-    ap.add_argument("--n", type=int, default=0, help="override n")
+    ap.add_argument("--ntrain", type=int, default=0, help="override n (not --n: ambiguous for torch.distributed.run)")
     ap.add_argument("--nstar", type=int, default=0, help="override n* (random test points instead of the grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
@@ -131,7 +131,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the gprc native path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("GPRC_FORCE_DIST") == "1"   # FORCE_DIST: exercise the RCCL path with one rank
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         comm = TorchComm()
@@ -141,8 +142,8 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
 
     n, d, kname, params, n_star = WORKLOADS[args.workload]
-    if args.n:
-        n = args.n
+    if args.ntrain:
+        n = args.ntrain
     if args.nstar:
         n_star = args.nstar
 
@@ -192,7 +193,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     nat.lib().gprc_prof_enable(0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -222,7 +223,7 @@ def main():
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_c4_pmc_traffic.json")))
-            if pm["kernel"] == symbol and pm["workload"] == args.workload and pm["n_gpus"] == world and not args.n and not args.nstar:
+            if pm["kernel"] == symbol and pm["workload"] == args.workload and pm["n_gpus"] == world and not args.ntrain and not args.nstar:
                 traffic = pm["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
@@ -255,7 +256,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(kname, params, d)
         print(json.dumps(out), flush=True)
     ops.close()
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 

@@ -277,7 +277,7 @@ class DistributedGPR:
         return 0
 
     def _bcast_panel(self, p):
-        if self.comm.world == 1:
+        if self.comm.world == 1 and not isinstance(self.comm, TorchComm):
             return
         g = self.geom
         src = p % self.comm.world
