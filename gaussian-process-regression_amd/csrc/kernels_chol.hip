@@ -438,15 +438,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc,
                                                          const double* B, int64_t ldb, int tiles_m, int tiles_n, int K,
                                                          int lower, int group) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+  // Normally one tile per workgroup (gridDim.x == ntiles).  GPRC_PERSIST=N launches N workgroups that walk the tile list
+  // with stride N instead (N a multiple of 8 keeps the XCD-contiguous id ranges); measured 4% slower at N=512.
+  const unsigned ntiles = (unsigned)tiles_m * (unsigned)tiles_n;
   const int width = group * tiles_n;
-  const int g = id / width, first_m = g * group;
-  const int gsize = (tiles_m - first_m < group) ? (tiles_m - first_m) : group;
-  const int tr = first_m + (int)(id % width) % gsize;
-  const int tc = (int)(id % width) / gsize;
-  if (lower && tc > tr) return;
-  gemm_tile_128<false>(C + (int64_t)tr * 128 + (int64_t)tc * 128 * ldc, ldc, A + (int64_t)tr * 128, lda,
-                       B + (int64_t)tc * 128, ldb, K, smem);
+  for (unsigned t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const unsigned id = xcd_remap(t, ntiles);
+    const int g = id / width, first_m = g * group;
+    const int gsize = (tiles_m - first_m < group) ? (tiles_m - first_m) : group;
+    const int tr = first_m + (int)(id % width) % gsize;
+    const int tc = (int)(id % width) / gsize;
+    if (lower && tc > tr) continue;
+    gemm_tile_128<false>(C + (int64_t)tr * 128 + (int64_t)tc * 128 * ldc, ldc, A + (int64_t)tr * 128, lda,
+                         B + (int64_t)tc * 128, ldb, K, smem);
+    __syncthreads();  // every wave has left the tile (LDS reads done) before the next tile's first DMA lands
+  }
 }
 
 // X[M x 128] := X * W^T (W = inverse of the diagonal block, lower triangular), in place: a workgroup
@@ -460,33 +466,36 @@ __global__ __launch_bounds__(256, 2) void trsm_panel_kernel(double* X, int64_t l
 // Trailing update over the packed layout: for every target panel q in {q_begin, q_begin+stride, ..}
 // C_q -= L_p[rows of q] * L_p[rows of q's diagonal block]^T, lower tiles only.
 __global__ __launch_bounds__(256, 2) void trailing_kernel(double* packed, int64_t n_pad, int p, int q_begin, int q_stride,
-                                                          int n_targets) {
+                                                          int n_targets, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int P = (int)(n_pad / NB);
-  int id = (int)xcd_remap(blockIdx.x, gridDim.x);
-  // locate the target panel: panel q holds TPP*TPP*(P-q) - TPP*(TPP-1)/2 lower tiles
   constexpr int DIAG_TILES = TPP * (TPP + 1) / 2;
-  int q = q_begin, s = 0;
-  for (; s < n_targets; ++s, q += q_stride) {
-    const int tq = TPP * TPP * (P - q) - TPP * (TPP - 1) / 2;
-    if (id < tq) break;
-    id -= tq;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {  // persistent, as gemm_nt_kernel
+    int id = (int)xcd_remap((unsigned)t, (unsigned)ntiles);
+    // locate the target panel: panel q holds TPP*TPP*(P-q) - TPP*(TPP-1)/2 lower tiles
+    int q = q_begin, s = 0;
+    for (; s < n_targets; ++s, q += q_stride) {
+      const int tq = TPP * TPP * (P - q) - TPP * (TPP - 1) / 2;
+      if (id < tq) break;
+      id -= tq;
+    }
+    if (s >= n_targets) continue;
+    int tr, tc;
+    if (id < DIAG_TILES) {  // the diagonal NB x NB block: lower tiles (0,0) (1,0) (1,1) (2,0) ...
+      tr = 0;
+      while ((tr + 1) * (tr + 2) / 2 <= id) ++tr;
+      tc = id - tr * (tr + 1) / 2;
+    } else {
+      tr = TPP + (id - DIAG_TILES) / TPP;
+      tc = (id - DIAG_TILES) % TPP;
+    }
+    const int64_t ldp = panel_ld(n_pad, p), ldq = panel_ld(n_pad, q);
+    const double* Lp = packed + panel_offset(n_pad, p) + (int64_t)(q - p) * NB;  // row q*NB of panel p
+    double* Cq = packed + panel_offset(n_pad, q);
+    gemm_tile_128<false>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, Lp + (int64_t)tr * 128, ldp,
+                         Lp + (int64_t)tc * 128, ldp, NB, smem);
+    __syncthreads();
   }
-  if (s >= n_targets) return;
-  int tr, tc;
-  if (id < DIAG_TILES) {  // the diagonal NB x NB block: lower tiles (0,0) (1,0) (1,1) (2,0) ...
-    tr = 0;
-    while ((tr + 1) * (tr + 2) / 2 <= id) ++tr;
-    tc = id - tr * (tr + 1) / 2;
-  } else {
-    tr = TPP + (id - DIAG_TILES) / TPP;
-    tc = (id - DIAG_TILES) % TPP;
-  }
-  const int64_t ldp = panel_ld(n_pad, p), ldq = panel_ld(n_pad, q);
-  const double* Lp = packed + panel_offset(n_pad, p) + (int64_t)(q - p) * NB;  // row q*NB of panel p
-  double* Cq = packed + panel_offset(n_pad, q);
-  gemm_tile_128<false>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, Lp + (int64_t)tr * 128, ldp,
-                       Lp + (int64_t)tc * 128, ldp, NB, smem);
 }
 
 }  // namespace
@@ -547,7 +556,8 @@ int launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64
   if (tiles > 0x7fffffff) { set_error("gemm_nt: too many tiles"); return GPRC_ERR_ARG; }
   const double useful = lower ? 0.5 : 1.0;  // algorithmic: the lower triangle only
   ProfScope ps(s, kind, 2.0 * M * N * K * useful, 8.0 * (2.0 * M * N * useful + (M + N) * (double)K));
-  const dim3 grid((unsigned)tiles), block(256);
+  static const int pg = std::getenv("GPRC_PERSIST") ? std::atoi(std::getenv("GPRC_PERSIST")) : 0;  // >0: persistent grid of that many workgroups (measured slower: DESIGN.md 6)
+  const dim3 grid((unsigned)((pg > 0 && tiles > pg) ? pg : tiles)), block(256);
   const size_t smem = G_SMEM_DOUBLES * sizeof(double);
   const int tm = (int)(M / 128), tn = (int)(N / 128);
   constexpr int group = 8;  // 8 x 8 concurrent tiles per XCD share 16 strips; 4..32 measured within 0.5 %
@@ -576,8 +586,10 @@ int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t
   }
   ProfScope ps(s, PK_TRAILING, fl, by);
 
-  hipLaunchKernelGGL(trailing_kernel, dim3((unsigned)tiles), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)p,
-                     (int)q_begin, (int)q_stride, (int)nt);
+  static const int pg = std::getenv("GPRC_PERSIST") ? std::atoi(std::getenv("GPRC_PERSIST")) : 0;
+  const unsigned grid = (unsigned)((pg > 0 && tiles > pg) ? pg : tiles);
+  hipLaunchKernelGGL(trailing_kernel, dim3(grid), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)p,
+                     (int)q_begin, (int)q_stride, (int)nt, (int)tiles);
   GPRC_LAUNCH_CHECK();
   return 0;
 }
