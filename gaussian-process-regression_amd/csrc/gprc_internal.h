@@ -17,6 +17,7 @@ constexpr int NB = GPRC_NB;  // outer panel width: K-depth of the trailing updat
 constexpr int NBI = 128;  // inner block: one LDS-resident diagonal factorisation, one GEMM tile edge
 constexpr int TPP = NB / NBI;  // 128-wide tile columns per panel
 constexpr int MAX_PARAMS = 64;
+constexpr int MAX_DEVICES = 64;  // per-device one-time setup flags
 static_assert(NB % NBI == 0 && NB >= NBI, "panel width must be a multiple of the 128 block");
 
 __host__ __device__ static inline int64_t pad_up(int64_t n, int64_t m) { return (n + m - 1) / m * m; }

@@ -507,11 +507,13 @@ int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* i
     // 8 column groups x 128 rows = 1024 threads; 4 and 2 groups (fatter threads) measured 6x and 9x slower
     hipLaunchKernelGGL(potf2_inv_kernel<8>, dim3(1), dim3(1024), 0, s, A, lda, winv, info_dev, col0);
   } else {
-    static bool attr_set = false;
+    static bool attr_set[MAX_DEVICES] = {};  // the attribute is per device: one process may hold contexts on several
     const size_t smem = PB_SMEM_DOUBLES * sizeof(double);
-    if (!attr_set) {
+    int dev = 0;
+    GPRC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES || !attr_set[dev]) {
       GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_blocked_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      attr_set = true;
+      if (dev >= 0 && dev < MAX_DEVICES) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(potf2_inv_blocked_kernel, dim3(1), dim3(1024), smem, s, A, lda, winv, info_dev, col0);
   }
@@ -520,20 +522,17 @@ int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* i
 }
 
 static int ensure_gemm_attrs() {
-  static bool done = false;
-  if (done) return 0;
-
-
-
-
+  static bool done[MAX_DEVICES] = {};  // per device, as above
+  int dev = 0;
+  GPRC_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < MAX_DEVICES && done[dev]) return 0;
   const int smem = (int)(G_SMEM_DOUBLES * sizeof(double));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<PK_GEMM_INNER>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<PK_SOLVE_UPDATE>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<PK_COV_SYRK>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-
-  done = true;
+  if (dev >= 0 && dev < MAX_DEVICES) done[dev] = true;
   return 0;
 }
 
