@@ -171,11 +171,21 @@ def main():
     eng, ops, bufs = make_engine(n, d, kname, params, X, y, Xs)
     lo, hi = eng.slice_bounds(ns, world)[rank]
 
+    marks = []   # (start, fitted, predicted) events on the library's main stream: phase split F1-F3 / P1-P3
+
+    def mark():
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(ops.main_stream)
+        return ev
+
     def step():
+        e0 = mark()
         info = eng.fit(bufs["X"], bufs["y"])
         if info != 0:
             raise RuntimeError(f"K + noise*I not positive definite (info={info})")
+        e1 = mark()
         eng.predict_local(bufs["X"], bufs["y"], bufs["Xs_local"], hi - lo, bufs["mean"], bufs["var"])
+        marks.append((e0, e1, mark()))
 
     def fence():
         ops.synchronize()
@@ -187,6 +197,7 @@ def main():
     nat.lib().gprc_prof_reset()
     nat.lib().gprc_prof_enable(1 if rank == 0 else 0)
     fence()
+    marks.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -247,6 +258,8 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC, separate pass)", "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["count"], 1)),
                          "launches": dom["count"], "avg_launch_ms": round(dom["ms"] / max(dom["count"], 1), 4)},
+            "phases_ms": {"fit_F1_F3": round(sum(a.elapsed_time(b) for a, b, _ in marks) / len(marks), 3),
+                          "predict_P1_P3": round(sum(b.elapsed_time(c) for _, b, c in marks) / len(marks), 3)},
             "kernels": kernels,
             "frac_of_fp64_peak_end_to_end": round(flops / (elapsed / args.steps) * 1e-12 / (FP64_MFMA_PEAK_TFLOPS * world), 4),
             "parity_gate_normwise_err": gate_err,

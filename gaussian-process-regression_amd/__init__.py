@@ -12,9 +12,9 @@ from .covfunc import (cov_func, covariance_matrix, constant, linear, polynomial,
 from .gpr import (GPR, GPR_constant, GPR_linear, GPR_polynomial, GPR_sqrexp, GPR_gammaexp,
                   GPR_rationalquadratic)
 from .gpc import GPC
-from .fit import fit, dens
+from .fit import fit, dens, dens_deriv
 
-__all__ = ["fit", "dens", "GPR", "GPR_constant", "GPR_linear", "GPR_polynomial", "GPR_sqrexp", "GPR_gammaexp",
+__all__ = ["fit", "dens", "dens_deriv", "GPR", "GPR_constant", "GPR_linear", "GPR_polynomial", "GPR_sqrexp", "GPR_gammaexp",
            "GPR_rationalquadratic", "GPC", "cov_func", "covariance_matrix", "constant", "linear", "polynomial",
            "sqrexp", "gammaexp", "rationalquadratic", "CovFunc", "GprcError", "NotPositiveDefinite", "Context",
            "default_context", "device_count"]

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "gprc_gpr_fit_retry": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, C.c_double, C.POINTER(_vp),
                                      C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "gprc_gpr_log_marginal": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, C.c_double, C.POINTER(C.c_double)]),
+    "gprc_fit_gradient": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, _dp]),
     "gprc_gpr_predict": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
     "gprc_model_dims": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "gprc_model_get_L": (C.c_int, [_vp, _vp, _i64]),
@@ -165,7 +166,7 @@ def device_count() -> int:
 
 
 PROF_KINDS = ["fill", "potf2_inv", "trsm_panel", "gemm_inner_k128", "trailing_update", "solve_update_k512", "trsv",
-              "row_reduce", "cov_syrk"]
+              "row_reduce", "cov_syrk", "deriv_rowsum"]
 
 
 def prof_summary():

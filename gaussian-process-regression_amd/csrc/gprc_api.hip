@@ -481,6 +481,55 @@ int gprc_gpr_log_marginal(gprc_ctx* ctx, int kernel, const double* params, int n
   return 0;
 }
 
+// dens_deriv(v) of R/fit.R:126-139, quirks included: K is the NOISE-FREE kernel matrix, alpha = K^-1 y, and
+//   grad_i = 0.5 * sum( diag(alpha alpha^T - K^-1) %*% dK/dv_i )  =  0.5 * sum_r (alpha_r^2 - (K^-1)_rr) * rowsum_r(dK/dv_i)
+// (a vector-matrix product where a trace is meant; `deriv` binds v positionally in its own argument order).
+// The reference inverts K with solve() (LU); here K = L L^T (K must be numerically positive definite, else info > 0,
+// which the host treats like solve()'s "computationally singular" error) and diag(K^-1)_r = sum_k (L^-1)_kr^2.
+int gprc_fit_gradient(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d, int64_t n,
+                      const double* y, double* grad_out) {
+  if (!grad_out) { set_error("fit_gradient: null output"); return GPRC_ERR_ARG; }
+  if (kernel != GPRC_SQREXP && kernel != GPRC_GAMMAEXP && kernel != GPRC_POLYNOMIAL && kernel != GPRC_RATQUAD) {
+    set_error("fit_gradient: defined for sqrexp, gammaexp, polynomial, rationalquadratic (R/fit.R:125)");
+    return GPRC_ERR_ARG;
+  }
+  gprc_model* m = nullptr;
+  GPRC_TRY(gpr_prepare(ctx, kernel, params, n_params, X, d, n, y, 0.0, &m));
+  struct Guard { gprc_model* m; ~Guard() { free_model(m); } } guard{m};
+  int info = 0;
+  GPRC_TRY(gpr_attempt(m, 0.0, &info));  // L, alpha = K^-1 y
+  if (info != 0) { set_error("fit_gradient: K is not positive definite (leading minor " + std::to_string(info) + ")"); return info; }
+  hipStream_t s = ctx->stream;
+  const int64_t n_pad = m->n_pad;
+  const int n_deriv = n_params;  // 1 (sqrexp) or 2
+  DevMem kinv, S;
+  GPRC_TRY(kinv.alloc(n_pad));
+  GPRC_TRY(S.alloc(2 * n));
+  // diag(K^-1): rows of L^-T, chunk by chunk
+  const int64_t rows = chunk_rows(ctx, n_pad, n);
+  double *vt = nullptr, *red = nullptr;
+  GPRC_TRY(ws_get(ctx, 0, rows * n_pad, &vt));
+  GPRC_TRY(ws_get(ctx, 1, rows * rowreduce_splits(n_pad), &red));
+  for (int64_t s0 = 0; s0 < n; s0 += rows) {
+    const int64_t mcur = std::min<int64_t>(rows, n - s0), m_pad = pad_up(mcur, 128);
+    GPRC_TRY(launch_set_identity_rows(s, vt, m_pad, m_pad, n_pad, s0));
+    GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt, m_pad, m_pad));
+    GPRC_TRY(launch_row_reduce(s, vt, m_pad, m_pad, n_pad, nullptr, kinv.p + s0, red));  // writes m_pad entries: kinv has n_pad
+  }
+  GPRC_TRY(launch_deriv_rowsum(s, kernel, params[0], n_params > 1 ? params[1] : 0.0, m->X, d, n, S.p));
+  std::vector<double> ha(n), hk(n), hs(2 * n);
+  GPRC_HIP(hipMemcpyAsync(ha.data(), m->alpha, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  GPRC_HIP(hipMemcpyAsync(hk.data(), kinv.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  GPRC_HIP(hipMemcpyAsync(hs.data(), S.p, sizeof(double) * n_deriv * n, hipMemcpyDeviceToHost, s));
+  GPRC_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < n_deriv; ++i) {
+    long double acc = 0.0L;
+    for (int64_t r = 0; r < n; ++r) acc += (long double)(ha[r] * ha[r] - hk[r]) * (long double)hs[(int64_t)i * n + r];
+    grad_out[i] = (double)(0.5L * acc);
+  }
+  return 0;
+}
+
 int gprc_gpr_fit_retry(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d,
                        int64_t n, const double* y, double noise, gprc_model** model_out, double* noise_used,
                        int* attempts) {

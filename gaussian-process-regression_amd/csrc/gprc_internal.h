@@ -42,7 +42,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 // ---- in-library event profiler (bench.py's live roofline numbers) ---------------------------------
 enum ProfKind { PK_FILL = 0, PK_POTF2 = 1, PK_TRSM_PANEL = 2, PK_GEMM_INNER = 3, PK_TRAILING = 4, PK_SOLVE_UPDATE = 5,
-                PK_TRSV = 6, PK_ROWREDUCE = 7, PK_COV_SYRK = 8, PK_COUNT = 9 };
+                PK_TRSV = 6, PK_ROWREDUCE = 7, PK_COV_SYRK = 8, PK_DERIV = 9, PK_COUNT = 10 };
 bool prof_enabled();
 void prof_begin(hipStream_t s, int kind);
 void prof_end(hipStream_t s, int kind, double flops, double bytes);
@@ -71,6 +71,10 @@ int launch_fill(hipStream_t s, const KernelSpec& ks, const double* A, int64_t nA
                 double* out, int64_t ld, int64_t row0, int64_t nrows, int64_t col0, int64_t ncols, PadMode mode,
                 double noise);
 int launch_colwise(hipStream_t s, const KernelSpec& ks, const double* x, const double* y, int64_t d, int64_t m, double* out);
+// S[r + n*i] = sum_c deriv_i(X[,r], X[,c]; v): row sums of the parameter derivatives of K(X,X) as cov_dict$...$deriv
+// (R/fit.R:4-31) defines them; n_deriv (1 or 2) components.  Kernels: sqrexp, gammaexp, polynomial, rationalquadratic.
+int launch_deriv_rowsum(hipStream_t s, int kernel, double v0, double v1, const double* X, int64_t d, int64_t n, double* S);
+int launch_set_identity_rows(hipStream_t s, double* vt, int64_t ld, int64_t rows, int64_t cols, int64_t row0);  // vt[i,j] = (row0+i == j)
 
 // ---- launchers (kernels_chol.hip) --------------------------------------------------------------
 // factor the 128x128 diagonal block at A (ld) in LDS, write L in place and its inverse to winv

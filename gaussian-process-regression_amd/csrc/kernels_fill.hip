@@ -183,6 +183,71 @@ int do_fill(hipStream_t s, const FillArgs& a) {
   }
 }
 
+// ---- derivative row sums for fit()'s gradient (R/fit.R:126-139) ---------------------------------------------------
+// deriv(x, y, v...) of cov_dict (R/fit.R:4-31), with v bound POSITIONALLY as the reference's do.call does:
+//   sqrexp (l)            r = |x-y| :  r^2/l^3 * exp(-r^2/(2 l^2))
+//   gammaexp (gamma, l)   r = |x-y| :  ( -exp(-(r/l)^gamma) (r/l)^gamma log(r/l) ,  exp(-(r/l)^gamma) gamma r^gamma / l^(gamma+1) )
+//   polynomial (sigma, p) s = x.y + sigma :  ( p s^(p-1) ,  s^p log(s) )
+//   rationalquadratic (alpha, l)  r = |x-y|^2, q = r/(2 l^2 alpha) + 1 :
+//                         ( q^-alpha (r - (2 l^2 alpha + r) log q) / (2 l^2 alpha + r) ,  r q^(-alpha-1) / l^3 )
+// (gammaexp's first component is 0 * -Inf = NaN at r = 0, i.e. on the diagonal: kept, it decides what optim does.)
+template <int KID>
+__device__ __forceinline__ void deriv_pair(double s, double v0, double v1, double& g0, double& g1) {
+  if constexpr (KID == GPRC_SQREXP) {
+    g0 = s / (v0 * v0 * v0) * exp(-s / ((v0 * v0) * 2.0));
+    g1 = 0.0;
+  } else if constexpr (KID == GPRC_GAMMAEXP) {
+    const double r = sqrt(s), rl = r / v1, e = exp(-r_pow(rl, v0));
+    g0 = -e * r_pow(rl, v0) * log(rl);
+    g1 = e * v0 * r_pow(r, v0) / r_pow(v1, v0 + 1.0);
+  } else if constexpr (KID == GPRC_POLYNOMIAL) {
+    const double t = s + v0;
+    g0 = v1 * r_pow(t, v1 - 1.0);
+    g1 = r_pow(t, v1) * log(t);
+  } else {  // rationalquadratic
+    const double c = 2.0 * (v1 * v1) * v0, q = s / c + 1.0;
+    g0 = (r_pow(q, -v0) * (s - (c + s) * log(q))) / (c + s);
+    g1 = (s * r_pow(q, -v0 - 1.0)) / (v1 * v1 * v1);
+  }
+}
+
+template <int KID>
+__global__ __launch_bounds__(256) void deriv_rowsum_kernel(double v0, double v1, const double* X, int64_t d, int64_t n, double* S) {
+  const int64_t r = blockIdx.x;
+  const double* xr = X + r * d;
+  double a0 = 0.0, a1 = 0.0;
+  for (int64_t c = threadIdx.x; c < n; c += 256) {
+    const double* xc = X + c * d;
+    double s = 0.0;
+    for (int64_t k = 0; k < d; ++k) {
+      if constexpr (KID == GPRC_POLYNOMIAL) s += xr[k] * xc[k];
+      else { const double t = xr[k] - xc[k]; s += t * t; }
+    }
+    double g0, g1;
+    deriv_pair<KID>(s, v0, v1, g0, g1);
+    a0 += g0;
+    a1 += g1;
+  }
+  __shared__ double red[2][4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a0 += __shfl_down(a0, off, 64);
+    a1 += __shfl_down(a1, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a0; red[1][threadIdx.x >> 6] = a1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    S[r] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    if (KID != GPRC_SQREXP) S[n + r] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void set_identity_rows_kernel(double* vt, int64_t ld, int64_t rows, int64_t cols, int64_t row0) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // row of the chunk (contiguous direction)
+  if (i >= rows) return;
+  for (int64_t j = blockIdx.y; j < cols; j += gridDim.y) vt[i + j * ld] = (row0 + i == j) ? 1.0 : 0.0;
+}
+
 }  // namespace
 
 int launch_fill(hipStream_t s, const KernelSpec& ks, const double* A, int64_t nA, const double* B, int64_t nB, int64_t d,
@@ -216,6 +281,28 @@ int launch_colwise(hipStream_t s, const KernelSpec& ks, const double* x, const d
     case GPRC_RATQUAD: hipLaunchKernelGGL((colwise_kernel<GPRC_RATQUAD>), grid, dim3(256), 0, s, ksd, x, y, d, m, out); break;
     default: set_error("unknown kernel id"); return GPRC_ERR_ARG;
   }
+  GPRC_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_deriv_rowsum(hipStream_t s, int kernel, double v0, double v1, const double* X, int64_t d, int64_t n, double* S) {
+  if (n <= 0) return 0;
+  ProfScope ps(s, PK_DERIV, (double)n * n * (3.0 * d + 40.0), 8.0 * ((double)n * d + 2.0 * n));
+  const dim3 grid((unsigned)n), block(256);
+  switch (kernel) {
+    case GPRC_SQREXP: hipLaunchKernelGGL((deriv_rowsum_kernel<GPRC_SQREXP>), grid, block, 0, s, v0, v1, X, d, n, S); break;
+    case GPRC_GAMMAEXP: hipLaunchKernelGGL((deriv_rowsum_kernel<GPRC_GAMMAEXP>), grid, block, 0, s, v0, v1, X, d, n, S); break;
+    case GPRC_POLYNOMIAL: hipLaunchKernelGGL((deriv_rowsum_kernel<GPRC_POLYNOMIAL>), grid, block, 0, s, v0, v1, X, d, n, S); break;
+    case GPRC_RATQUAD: hipLaunchKernelGGL((deriv_rowsum_kernel<GPRC_RATQUAD>), grid, block, 0, s, v0, v1, X, d, n, S); break;
+    default: set_error("fit gradient: the reference defines it for sqrexp, gammaexp, polynomial, rationalquadratic only (R/fit.R:125)"); return GPRC_ERR_ARG;
+  }
+  GPRC_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_set_identity_rows(hipStream_t s, double* vt, int64_t ld, int64_t rows, int64_t cols, int64_t row0) {
+  if (rows <= 0 || cols <= 0) return 0;
+  hipLaunchKernelGGL(set_identity_rows_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)(cols < 4096 ? cols : 4096)), dim3(256), 0, s, vt, ld, rows, cols, row0);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

@@ -107,6 +107,16 @@ GPRC_API int gprc_gpr_fit_retry(gprc_ctx* ctx, int kernel, const double* params,
  * the Cholesky's own info is the same test in exact arithmetic. */
 GPRC_API int gprc_gpr_log_marginal(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d,
                           int64_t n, const double* y, double noise, double* logp_out);
+/* dens_deriv(v), the gradient fit() hands to optim(method = "BFGS") (R/fit.R:126-139), reproduced with its quirks:
+ * K is the NOISE-FREE kernel matrix, alpha = K^-1 y, and component i is
+ *   0.5 * sum( diag(alpha alpha^T - K^-1) %*% dK/dv_i )      -- a vector %*% matrix, not a trace (:138);
+ * dK/dv comes from cov_dict$<kernel>$deriv (R/fit.R:4-31) with v bound positionally in deriv's OWN argument order
+ * (gammaexp: (gamma, l), rationalquadratic: (alpha, l) -- the opposite of the kernels' own order, :10,25).
+ * Defined for sqrexp, gammaexp, polynomial, rationalquadratic (:125).  gammaexp's first component is NaN by
+ * construction (0 * log 0 on the diagonal).  grad_out: n_params doubles in HOST memory.  Returns 0, or info > 0 when
+ * K is not (numerically) positive definite -- the reference's solve(K) fails there with "computationally singular". */
+GPRC_API int gprc_fit_gradient(gprc_ctx* ctx, int kernel, const double* params, int n_params, const double* X, int64_t d,
+                      int64_t n, const double* y, double* grad_out);
 /* GPR$predict (R/GPRclass.R:155-170).  X_star is d x n_star.
  * pointwise != 0: mean_out[n_star], var_out[n_star] = k(x*,x*) - colSums(v*v)      (:164-165)
  * pointwise == 0: mean_out[n_star], var_out = n_star x n_star K(X*,X*) - t(v) %*% v (:167-168) */

@@ -515,3 +515,112 @@ ORACLE_API int oracle_gpr_fit_predict_blocked(int id, const double* par, int npa
   }
   return 0;
 }
+
+/* ================================================================================================
+ * fit(): gradient of the log marginal likelihood as the reference computes it (R/fit.R:126-139).
+ * ============================================================================================== */
+
+/* cov_dict$<kernel>$deriv (R/fit.R:4-31); v is bound positionally in deriv's own argument order:
+ * sqrexp (l) :4-7, gammaexp (gamma, l) :10-13, polynomial (sigma, p) :21-23, rationalquadratic (alpha, l) :26-31.
+ * Note rationalquadratic's r is the SQUARED distance (:27), the others' r the distance.  out has npar entries. */
+static void deriv_pair(int id, const double* v, const double* x, const double* y, int64_t d, double* out) {
+  if (id == K_POLYNOMIAL) {
+    double xy = 0.0; /* x %*% y */
+    for (int64_t k = 0; k < d; ++k) xy += x[k] * y[k];
+    double t = xy + v[0];
+    out[0] = v[1] * r_pow(t, v[1] - 1.0);
+    out[1] = r_pow(t, v[1]) * log(t);
+    return;
+  }
+  ldbl s = 0.0L; /* sum((x - y)^2) */
+  for (int64_t k = 0; k < d; ++k) { double df = x[k] - y[k]; s += (ldbl)(df * df); }
+  double ss = (double)s;
+  if (id == K_SQREXP) {
+    double r = sqrt(ss), l = v[0];
+    out[0] = r_pow(r, 2.0) / r_pow(l, 3.0) * exp(-r_pow(r, 2.0) / (r_pow(l, 2.0) * 2.0));
+  } else if (id == K_GAMMAEXP) {
+    double r = sqrt(ss), g = v[0], l = v[1];
+    out[0] = -exp(-r_pow(r / l, g)) * r_pow(r / l, g) * log(r / l);
+    out[1] = exp(-r_pow(r / l, g)) * g * r_pow(r, g) / r_pow(l, g + 1.0);
+  } else { /* K_RATQUAD */
+    double r = ss, a = v[0], l = v[1];
+    double c = 2.0 * r_pow(l, 2.0) * a;
+    out[0] = (r_pow(r / c + 1.0, -a) * (r - (c + r) * log(r / c + 1.0))) / (c + r);
+    out[1] = (r * r_pow(r / c + 1.0, -a - 1.0)) / r_pow(l, 3.0);
+  }
+}
+
+/* solve(K): LU with partial pivoting applied to the identity (what dgesv does).  Returns 1 on an exactly zero
+ * pivot.  R additionally refuses when the estimated rcond < .Machine$double.eps; that estimate is not restated. */
+static int lu_inverse(double* A, int64_t n, double* inv) {
+  int64_t* piv = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
+  if (!piv) return -1;
+  for (int64_t k = 0; k < n; ++k) {
+    int64_t pr = k;
+    double best = fabs(A[k + k * n]);
+    for (int64_t i = k + 1; i < n; ++i)
+      if (fabs(A[i + k * n]) > best) { best = fabs(A[i + k * n]); pr = i; }
+    piv[k] = pr;
+    if (best == 0.0 || best != best) { free(piv); return 1; }
+    if (pr != k)
+      for (int64_t j = 0; j < n; ++j) { double t = A[k + j * n]; A[k + j * n] = A[pr + j * n]; A[pr + j * n] = t; }
+    double pv = 1.0 / A[k + k * n];
+    for (int64_t i = k + 1; i < n; ++i) A[i + k * n] *= pv;
+    for (int64_t j = k + 1; j < n; ++j) {
+      double akj = A[k + j * n];
+      for (int64_t i = k + 1; i < n; ++i) A[i + j * n] -= A[i + k * n] * akj;
+    }
+  }
+  for (int64_t c = 0; c < n; ++c) {
+    double* b = inv + c * n;
+    for (int64_t i = 0; i < n; ++i) b[i] = (i == c) ? 1.0 : 0.0;
+    for (int64_t k = 0; k < n; ++k)
+      if (piv[k] != k) { double t = b[k]; b[k] = b[piv[k]]; b[piv[k]] = t; }
+    for (int64_t k = 0; k < n; ++k) /* L y = P b, unit lower */
+      for (int64_t i = k + 1; i < n; ++i) b[i] -= A[i + k * n] * b[k];
+    for (int64_t k = n - 1; k >= 0; --k) { /* U x = y */
+      b[k] /= A[k + k * n];
+      for (int64_t i = 0; i < k; ++i) b[i] -= A[i + k * n] * b[k];
+    }
+  }
+  free(piv);
+  return 0;
+}
+
+/* dens_deriv(v)  --  R/fit.R:126-139.  `par` is v (the kernel is evaluated with it in the kernel's argument order
+ * :132, deriv with it in deriv's order :133).  grad has npar entries.  Returns 0, 1 (singular K), <0 (argument). */
+ORACLE_API int oracle_fit_gradient(int id, const double* par, int npar, const double* X, int64_t d, int64_t n,
+                                   const double* y, double* grad) {
+  if (!(id == K_SQREXP || id == K_GAMMAEXP || id == K_POLYNOMIAL || id == K_RATQUAD) || !check_params(id, npar, d)) return -1;
+  double* K = (double*)malloc(sizeof(double) * (size_t)(n * n));
+  double* Kd = (double*)malloc(sizeof(double) * (size_t)(n * n * npar));
+  double* Kinv = (double*)malloc(sizeof(double) * (size_t)(n * n));
+  double* alpha = (double*)malloc(sizeof(double) * (size_t)n);
+  if (!K || !Kd || !Kinv || !alpha) { free(K); free(Kd); free(Kinv); free(alpha); return -2; }
+  for (int64_t i = 0; i < n; ++i)     /* :130-135 */
+    for (int64_t j = 0; j < n; ++j) {
+      double g[2] = {0.0, 0.0};
+      K[i + j * n] = kernel_pair(id, par, npar, X + i * d, X + j * d, d);
+      deriv_pair(id, par, X + i * d, X + j * d, d, g);
+      for (int k = 0; k < npar; ++k) Kd[i + j * n + (int64_t)k * n * n] = g[k];
+    }
+  int rc = lu_inverse(K, n, Kinv);    /* :136  K_inv <- solve(K) */
+  if (rc == 0) {
+    for (int64_t i = 0; i < n; ++i) { /* :137  alpha <- K_inv %*% y */
+      double s = 0.0;
+      for (int64_t j = 0; j < n; ++j) s += Kinv[i + j * n] * y[j];
+      alpha[i] = s;
+    }
+    for (int k = 0; k < npar; ++k) {  /* :138  0.5 * sum(diag(alpha %*% t(alpha) - K_inv) %*% K_deriv[,,i]) */
+      ldbl total = 0.0L;
+      for (int64_t c = 0; c < n; ++c) {
+        double s = 0.0;
+        for (int64_t r = 0; r < n; ++r) s += (alpha[r] * alpha[r] - Kinv[r + r * n]) * Kd[r + c * n + (int64_t)k * n * n];
+        total += (ldbl)s;
+      }
+      grad[k] = (double)(0.5L * total);
+    }
+  }
+  free(K); free(Kd); free(Kinv); free(alpha);
+  return rc;
+}

@@ -202,3 +202,19 @@ def gpr_fit_predict_blocked(kid, params, X, y, noise, Xs):
     info = fn(C.c_int(kid), pp, npar, _p(X), _i64(d), _i64(n), _p(y), C.c_double(noise), _p(Xs), _i64(ns), _p(L), _p(work),
               _p(alpha), C.byref(logp), _p(mean), _p(var))
     return dict(info=info, L=np.tril(L), alpha=alpha, logp=logp.value, mean=mean, var=var)
+
+
+def fit_gradient(kid, params, X, y):
+    """dens_deriv(v) of R/fit.R:126-139 (noise-free K, LU inverse, the diag %*% quirk).  Raises ArithmeticError when
+    K is singular."""
+    X = _as_points(X)
+    d, n = X.shape
+    y = np.ascontiguousarray(np.asarray(y, dtype=np.float64))
+    p, pp, npar = _par(params)
+    g = np.empty(p.size)
+    rc = lib().oracle_fit_gradient(C.c_int(kid), pp, npar, _p(X), _i64(d), _i64(n), _p(y), _p(g))
+    if rc == 1:
+        raise ArithmeticError("system is exactly singular")
+    if rc:
+        raise ValueError(f"oracle_fit_gradient rc={rc}")
+    return g

@@ -75,3 +75,64 @@ def test_fit_optimum_matches_independent_optimiser():
     g = GPR(X, y, 0.05, r["func"])
     g2 = GPR(X, y, 0.05, cov_names=["sqrexp"])
     assert nerr(g2.alpha, g.alpha) == 0.0 and g2.k.gprc_kernel[1][0] == r["par"][0]
+
+
+def test_fit_gradient_matches_the_reference_formula():
+    """gprc_fit_gradient against the oracle's line-by-line restatement of R/fit.R:126-139 (noise-free K, the
+    diag(.) %*% quirk, deriv's own parameter order).  The native path inverts K through its Cholesky factor, the
+    reference through LU: same numbers on well-conditioned K, which is what these cases are."""
+    from gprc_amd import dens_deriv
+    rng = np.random.default_rng(21)
+    Xr = rng.uniform(-1, 1, (3, 200))
+    yr = rng.normal(size=200)
+    for name, kid, v in [("sqrexp", orc.SQREXP, [0.15]), ("rationalquadratic", orc.RATQUAD, [0.2, 0.7]),
+                         ("rationalquadratic", orc.RATQUAD, [0.3, 2.5])]:
+        ref = orc.fit_gradient(kid, v, Xr, yr)
+        got = dens_deriv(Xr, yr, name, v)
+        assert got.shape == ref.shape and np.max(np.abs(got - ref)) <= 1e-9 * np.max(np.abs(ref)), (name, got, ref)
+    with np.errstate(all="ignore"):
+        ref = orc.fit_gradient(orc.GAMMAEXP, [0.2, 1.5], Xr, yr)
+        got = dens_deriv(Xr, yr, "gammaexp", [0.2, 1.5])
+    assert np.isnan(ref[0]) and np.isnan(got[0])                      # 0 * log(0) on the diagonal, R/fit.R:12
+    assert abs(got[1] - ref[1]) <= 1e-9 * abs(ref[1])
+    Xp, yp = np.array([[0.2, 0.9, 1.7]]), np.array([1.0, -0.5, 0.3])  # polynomial p = 2: K has rank 3, n = 3
+    ref = orc.fit_gradient(orc.POLYNOMIAL, [0.5, 2.0], Xp, yp)
+    got = dens_deriv(Xp, yp, "polynomial", [0.5, 2.0])
+    assert np.max(np.abs(got - ref)) <= 1e-6 * np.max(np.abs(ref))   # cond(K) ~ 1e3..1e4 at n = 3
+    with pytest.raises(NotPositiveDefinite):                          # duplicate points: K singular, solve(K) fails in R
+        dens_deriv(np.array([[0.0, 0.0, 1.0]]), np.array([1.0, 2.0, 3.0]), "sqrexp", [1.0])
+    with pytest.raises(Exception, match="sqrexp, gammaexp, polynomial, rationalquadratic"):
+        dens_deriv(Xp, yp, "linear", [1.0])
+
+
+def test_fit_bfgs_kernels_follow_the_reference_driver():
+    """gammaexp / rationalquadratic: optim(method = "BFGS") with dens_deriv (R/fit.R:125-140,144,157-158).  The
+    native fit() against the same vmmin + optim_until_error driver fed by the ORACLE's objective and gradient."""
+    from gprc_amd.fit import _optim_bfgs_until_error
+
+    def oracle_driver(kid, Xd, yd, noise):
+        def dens_o(v):
+            f = orc.gpr_fit(kid, list(v), Xd, yd, noise)
+            if f["attempts"] != 1:
+                raise ArithmeticError("not positive definite")
+            return f["logp"]
+        with np.errstate(all="ignore"):
+            return _optim_bfgs_until_error((1.0, 1.0), dens_o, lambda v: orc.fit_gradient(kid, list(v), Xd, yd))
+
+    for seed, d, n in [(1, 2, 40), (5, 3, 60)]:                       # the first stalls at the start, the second moves
+        rng = np.random.default_rng(seed)
+        Xd = rng.uniform(-3, 3, (d, n))
+        yd = np.sin(Xd.sum(0)) + 0.1 * rng.normal(size=n)
+        ref_par, ref_val = oracle_driver(orc.RATQUAD, Xd, yd, 0.1)
+        r = fit(Xd, yd, 0.1, ["rationalquadratic"])
+        assert r["cov"] == "rationalquadratic" and len(r["par"]) == 2
+        assert np.allclose(r["par"], ref_par, rtol=1e-6, atol=1e-9), (seed, r["par"], ref_par)
+        assert abs(r["score"][0] - ref_val) <= 1e-8 * abs(ref_val)
+    # gammaexp: the NaN gradient component makes vmmin stop at once -- fit() returns the start values (1, 1)
+    r = fit(Xd, yd, 0.1, ["gammaexp"])
+    assert r["par"] == (1.0, 1.0)
+    assert abs(r["score"][0] - orc.gpr_fit(orc.GAMMAEXP, [1.0, 1.0], Xd, yd, 0.1)["logp"]) <= 1e-10 * abs(r["score"][0])
+    # the full default list (R/fit.R:110) now runs end to end and the closure drives GPR
+    full = fit(Xd, yd, 0.1)
+    assert full["cov"] in ("sqrexp", "gammaexp", "constant", "linear", "polynomial", "rationalquadratic") and len(full["score"]) == 6
+    assert GPR(Xd, yd, 0.1, full["func"]).predict(Xd[:, :5]).shape == (5, 2)

@@ -1,6 +1,8 @@
 """Host-side logic that needs no GPU: cov_func argument matching and tagging, argument validation in the
 reference's stopifnot() order, read-only bindings, packed-layout index arithmetic, and the loud failure of
 the compute path when no MI355X is present (no CPU fallback)."""
+import math
+
 import numpy as np
 import pytest
 
@@ -61,8 +63,9 @@ def test_argument_validation_mirrors_stopifnot():
         GPR(X, np.zeros(3), 0.1, k)                              # length(y) == ncol(X)
     with pytest.raises(TypeError):
         GPR(X, y, 0.1, 3.0)                                      # is.function(k)
-    with pytest.raises(NotImplementedError):
-        GPR(X, y, 0.1)                                           # default k = fit(...)$func: SURVEY 8f "next"
+    if not gpu_available():
+        with pytest.raises(GprcError, match="no CPU fallback"):
+            GPR(X, y, 0.1)                                       # default k = fit(...)$func runs the native objective
     with pytest.raises(TypeError):
         GPC(X, y, k, epsilon=0.0)                                # epsilon > 0
     with pytest.raises(ValueError):
@@ -150,9 +153,49 @@ def test_brent_fmin_restatement_against_scipy():
     assert abs(calls[0] - (0 + (3 - math.sqrt(5)) / 2 * 10)) < 1e-15      # first probe: the golden-section point
 
 
-def test_fit_rejects_bfgs_kernels_loudly():
-    from gprc_amd import fit
-    with pytest.raises(NotImplementedError, match="BFGS"):
-        fit(np.zeros((1, 4)), np.zeros(4), 0.1)                            # default list includes gammaexp / rationalquadratic
-    with pytest.raises(NotImplementedError):
-        fit(np.zeros((1, 4)), np.zeros(4), 0.1, ["sqrexp", "rationalquadratic"])
+def test_vmmin_reproduces_the_documented_optim_example():
+    """?optim's own example: optim(c(-1.2, 1), fr, grr, method = "BFGS") on the Rosenbrock banana reports
+    $value 9.594956e-18, $counts function 110 / gradient 43, $convergence 0 -- the known answer for the restatement."""
+    from gprc_amd.fit import vmmin
+    fr = lambda v: 100 * (v[1] - v[0] ** 2) ** 2 + (1 - v[0]) ** 2
+    grr = lambda v: np.array([-400 * v[0] * (v[1] - v[0] ** 2) - 2 * (1 - v[0]), 200 * (v[1] - v[0] ** 2)])
+    par, val, nf, ng, fail = vmmin([-1.2, 1.0], fr, grr)
+    assert (nf, ng, fail) == (110, 43, 0)
+    assert abs(val - 9.594956e-18) <= 1e-23 and np.allclose(par, [1.0, 1.0], atol=1e-7)
+    # a search direction that is not downhill -- here because one gradient component is NaN, as gammaexp's is in
+    # R/fit.R:12 -- terminates at once at the start value (the "uphill" exit right after the initial reset)
+    par, val, nf, ng, fail = vmmin([1.0, 1.0], fr, lambda v: np.array([np.nan, 1.0]))
+    assert par.tolist() == [1.0, 1.0] and (nf, ng, fail) == (1, 1, 0)
+    with pytest.raises(ArithmeticError, match="not finite"):
+        vmmin([1.0, 1.0], lambda v: math.inf, grr)
+
+
+def test_optim_until_error_bfgs_semantics():
+    """R/fit.R:47-69 with method = "BFGS": the sentinel wraps f only; an error in gr aborts optim and the best
+    successful evaluation so far is returned; with none, (start, f(start))."""
+    from gprc_amd.fit import SENTINEL, _optim_bfgs_until_error
+    f = lambda v: -((v[0] - 2.0) ** 2 + (v[1] + 1.0) ** 2)                 # maximum 0 at (2, -1)
+    gr = lambda v: np.array([-2 * (v[0] - 2.0), -2 * (v[1] + 1.0)])
+    par, val = _optim_bfgs_until_error((1.0, 1.0), f, gr)
+    assert np.allclose(par, [2.0, -1.0], atol=1e-6) and abs(val) < 1e-10
+    calls = {"g": 0}
+
+    def gr_fails_later(v):
+        calls["g"] += 1
+        if calls["g"] > 1:
+            raise ArithmeticError("computationally singular")
+        return gr(v)
+    seen = []
+    par, val = _optim_bfgs_until_error((1.0, 1.0), lambda v: (seen.append((tuple(v), f(v))) or seen[-1][1]), gr_fails_later)
+    best = max(seen, key=lambda t: t[1])
+    assert par == best[0] and val == best[1] and len(seen) >= 2           # best-so-far, not the start value
+
+    def gr_fails(v):
+        raise ArithmeticError("computationally singular")
+    par, val = _optim_bfgs_until_error((1.0, 1.0), f, gr_fails)            # f(start) was recorded before gr failed
+    assert par == (1.0, 1.0) and val == f((1.0, 1.0))
+
+    def f_fails(v):
+        raise ArithmeticError("not positive definite")
+    par, val = _optim_bfgs_until_error((1.0, 1.0), f_fails, gr_fails)      # nothing recorded: (start, sentinel)
+    assert par == (1.0, 1.0) and val == SENTINEL

@@ -144,3 +144,45 @@ def test_kernel_colwise_matches_matrix_diagonal():
     for kid, par in [(orc.CONSTANT, [2.0]), (orc.LINEAR, [0.3, 0.6, 0.9]), (orc.POLYNOMIAL, [0.5, 2.0]), (orc.SQREXP, [0.7]),
                      (orc.GAMMAEXP, [0.7, 1.3]), (orc.RATQUAD, [0.7, 2.5])]:
         assert np.array_equal(orc.kernel_colwise(kid, par, A, B), np.diag(orc.kernel_matrix(kid, par, A, B)))
+
+
+def test_fit_gradient_restatement_against_literal_numpy():
+    """oracle_fit_gradient (R/fit.R:126-139) against a line-by-line numpy transcription of the same R expressions
+    (np.linalg.inv for solve).  Unpinned by the reference: it holds no numbers for fit()."""
+    rng = np.random.default_rng(4)
+    d, n = 2, 30
+    X = rng.uniform(-3, 3, (d, n))
+    y = rng.normal(size=n)
+
+    def literal(kid, v, deriv):
+        K = orc.kernel_matrix(kid, v, X, X)                                             # :132
+        Kd = np.array([[deriv(X[:, i], X[:, j], *v) for j in range(n)] for i in range(n)]).reshape(n, n, len(v))  # :133
+        Ki = np.linalg.inv(K)                                                           # :136
+        al = Ki @ y                                                                     # :137
+        return np.array([0.5 * np.sum(np.diag(np.outer(al, al) - Ki) @ Kd[:, :, i]) for i in range(len(v))])  # :138
+
+    def d_sqrexp(x, yy, l):                                                             # R/fit.R:4-7
+        r = np.sqrt(np.sum((x - yy) ** 2))
+        return [r ** 2 / l ** 3 * np.exp(-r ** 2 / (l ** 2 * 2))]
+
+    def d_ratquad(x, yy, alpha, l):                                                     # R/fit.R:25-31
+        r = np.sum((x - yy) ** 2)
+        q = r / (2 * l ** 2 * alpha) + 1
+        return [(q ** (-alpha) * (r - (2 * l ** 2 * alpha + r) * np.log(q))) / (2 * l ** 2 * alpha + r),
+                (r * q ** (-alpha - 1)) / l ** 3]
+
+    def d_poly(x, yy, sigma, p):                                                        # R/fit.R:20-23
+        s = x @ yy + sigma
+        return [p * s ** (p - 1), s ** p * np.log(s)]
+
+    for kid, v, dv in [(orc.SQREXP, [0.5], d_sqrexp), (orc.RATQUAD, [0.7, 1.3], d_ratquad), (orc.RATQUAD, [1.0, 1.0], d_ratquad)]:
+        got, ref = orc.fit_gradient(kid, v, X, y), literal(kid, v, dv)
+        assert np.max(np.abs(got - ref)) <= 1e-9 * np.max(np.abs(ref)), (kid, v)
+    Xp = np.array([[0.2, 0.9, 1.7]])                                                    # polynomial: K has rank p + 1, keep n = 3
+    yp = np.array([1.0, -0.5, 0.3])
+    X, y, n = Xp, yp, 3
+    got, ref = orc.fit_gradient(orc.POLYNOMIAL, [0.5, 2.0], Xp, yp), literal(orc.POLYNOMIAL, [0.5, 2.0], d_poly)
+    assert np.max(np.abs(got - ref)) <= 1e-7 * np.max(np.abs(ref))
+    # gammaexp: -exp(.) * (r/l)^gamma * log(r/l) is 0 * -Inf = NaN at r = 0, i.e. on every diagonal entry (R/fit.R:12)
+    g = orc.fit_gradient(orc.GAMMAEXP, [1.0, 1.0], rng.uniform(-3, 3, (2, 10)), rng.normal(size=10))
+    assert math.isnan(g[0]) and math.isfinite(g[1])
