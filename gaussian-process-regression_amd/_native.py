@@ -91,6 +91,9 @@ PROTOTYPES = {
     "gprc_dev_logp": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "gprc_gpr_model_from_device": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, _vp, _vp, _vp, C.c_double,
                                              C.c_double, C.POINTER(_vp)]),
+    "gprc_mvn_factor": (C.c_int, [_vp, _vp, _i64, _i64, C.c_double, _vp, C.POINTER(C.c_int)]),
+    "gprc_mvn_sample": (C.c_int, [_vp, _vp, _i64, _i64, _vp, C.c_double, _vp, _i64, _vp, C.POINTER(C.c_int)]),
+    "gprc_sym_eigen": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, C.POINTER(C.c_int)]),
     "gprc_prof_enable": (C.c_int, [C.c_int]),
     "gprc_prof_reset": (C.c_int, []),
     "gprc_prof_kinds": (C.c_int, []),
@@ -166,7 +169,7 @@ def device_count() -> int:
 
 
 PROF_KINDS = ["fill", "potf2_inv", "trsm_panel", "gemm_inner_k128", "trailing_update", "solve_update_k512", "trsv",
-              "row_reduce", "cov_syrk", "deriv_rowsum"]
+              "row_reduce", "cov_syrk", "deriv_rowsum", "jacobi_sweep"]
 
 
 def prof_summary():

@@ -5,6 +5,7 @@
 // `.Call` case) and uses device pointers in place (the resident-data case).  No CPU arithmetic on
 // matrices happens here: without a gfx950 device every entry point fails with GPRC_ERR_NO_DEVICE /
 // GPRC_ERR_HIP.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -318,6 +319,87 @@ int gpr_prepare(gprc_ctx* ctx, int kernel, const double* params, int n_params, c
   if (e == hipSuccess) e = hipMemcpyAsync(m->y, y, sizeof(double) * n, hipMemcpyDefault, s);
   if (e != hipSuccess) { free_model(m); return hip_fail(e, "copy X,y", __FILE__, __LINE__); }
   *mout = m;
+  return 0;
+}
+
+// eigen(A, symmetric = TRUE) on the device: cyclic Jacobi (kernels_eig.hip).  A_dev: m x m, lower triangle read.
+// On return V_dev (m x m) holds the eigenvectors in Jacobi order, `values` the matching eigenvalues and `perm` the
+// column order that makes them decreasing (R's convention).
+int sym_eigen_dev(gprc_ctx* ctx, const double* A_dev, int64_t lda, int64_t m, double* V_dev, std::vector<double>& values,
+                  std::vector<int>& perm, int* sweeps_out) {
+  if (m < 1 || m > 16384) { set_error("eigen: m must be in [1, 16384]"); return GPRC_ERR_ARG; }
+  hipStream_t s = ctx->stream;
+  DevMem W, cs, od;
+  GPRC_TRY(W.alloc(m * m));
+  GPRC_TRY(cs.alloc(m + 2));
+  GPRC_TRY(od.alloc(2 * m));
+  GPRC_TRY(launch_sym_copy(s, A_dev, lda, m, W.p, V_dev));
+  std::vector<double> h(2 * m);
+  int sweeps = 0;
+  for (;; ++sweeps) {
+    GPRC_TRY(launch_jacobi_offnorm(s, W.p, (int)m, od.p, od.p + m));
+    GPRC_HIP(hipMemcpyAsync(h.data(), od.p, sizeof(double) * 2 * m, hipMemcpyDeviceToHost, s));
+    GPRC_HIP(hipStreamSynchronize(s));
+    long double off2 = 0.0L, dg2 = 0.0L;
+    bool finite = true;
+    for (int64_t j = 0; j < m; ++j) { off2 += h[j]; dg2 += (long double)h[m + j] * h[m + j]; finite = finite && std::isfinite(h[j]) && std::isfinite(h[m + j]); }
+    if (!finite) { set_error("eigen: matrix has non-finite entries"); return GPRC_ERR_ARG; }
+    // ||off||_F <= max(1e-15, m eps) ||A||_F: below m*eps the off-diagonal part is rounding noise of the rotations
+    // themselves (a rank-deficient covariance keeps ~m^2 such entries alive in its null space) and never shrinks
+    const long double rel = std::max(1e-15L, (long double)m * 2.220446049250313e-16L);
+    if (off2 <= rel * rel * (off2 + dg2) || sweeps >= 40) break;
+    if (m > 1) GPRC_TRY(launch_jacobi_sweep(s, W.p, V_dev, (int)m, cs.p));
+  }
+  values.assign(h.begin() + m, h.end());
+  perm.resize(m);
+  for (int64_t j = 0; j < m; ++j) perm[j] = (int)j;
+  std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return values[a] > values[b]; });
+  if (sweeps_out) *sweeps_out = sweeps;
+  return 0;
+}
+
+// t(chol(cov)) or, when that fails, eigen$vectors %*% diag(sqrt(pmax(eigen$values, 0)))  (R/GPRclass.R:362-368).
+// L_dev: m x m (ld m).  *method: 1 Cholesky (L lower triangular), 2 eigen.
+int mvn_factor_dev(gprc_ctx* ctx, const double* cov_dev, int64_t ld, int64_t m, double tol, double* L_dev, int* method) {
+  hipStream_t s = ctx->stream;
+  const int64_t n_pad = pad_up(m, NB);
+  {
+    DevMem packed, winv;
+    GPRC_TRY(packed.alloc(gprc_packed_size(n_pad)));
+    GPRC_TRY(winv.alloc(gprc_winv_size(n_pad)));
+    GPRC_TRY(launch_pack_dense(s, cov_dev, ld, m, n_pad, packed.p));
+    int info = 0;
+    GPRC_TRY(factor_all(ctx, packed.p, n_pad, winv.p, &info));
+    if (info == 0) {
+      GPRC_TRY(launch_unpack_L(s, packed.p, n_pad, m, L_dev, m));
+      GPRC_HIP(hipStreamSynchronize(s));
+      *method = 1;
+      return 0;
+    }
+  }
+  DevMem V, scale;
+  struct IntMem { int* p = nullptr; ~IntMem() { if (p) (void)hipFree(p); } } permd;
+  GPRC_TRY(V.alloc(m * m));
+  GPRC_TRY(scale.alloc(m));
+  GPRC_HIP(hipMalloc(&permd.p, sizeof(int) * (size_t)m));
+  std::vector<double> values;
+  std::vector<int> perm;
+  GPRC_TRY(sym_eigen_dev(ctx, cov_dev, ld, m, V.p, values, perm, nullptr));
+  std::vector<double> sc(m);
+  const double lead = std::fabs(values[perm[0]]);
+  for (int64_t k = 0; k < m; ++k) {
+    const double ev = values[perm[k]];
+    if (!(ev > -tol * lead)) {  // stopifnot(all(eigval > -tol * abs(eigval[1])))  :366
+      set_error("multivariate_normal: covariance is not positive semi-definite (eigenvalue " + std::to_string(ev) + ")");
+      return GPRC_ERR_NOT_PD;
+    }
+    sc[k] = std::sqrt(ev > 0.0 ? ev : 0.0);
+  }
+  GPRC_HIP(hipMemcpyAsync(scale.p, sc.data(), sizeof(double) * m, hipMemcpyHostToDevice, s));
+  GPRC_HIP(hipMemcpyAsync(permd.p, perm.data(), sizeof(int) * m, hipMemcpyHostToDevice, s));
+  GPRC_TRY(launch_gather_scale_cols(s, V.p, (int)m, permd.p, scale.p, L_dev, m));
+  GPRC_HIP(hipStreamSynchronize(s));
+  *method = 2;
   return 0;
 }
 
@@ -880,6 +962,74 @@ int gprc_dev_row_reduce(gprc_ctx* ctx, const double* vt, int64_t ld, int64_t row
                         double* out, double* work) {
   GPRC_TRY(use_device(ctx));
   return launch_row_reduce(ctx->stream, vt, ld, rows, cols, w, out, work);
+}
+
+// ---- sampling -----------------------------------------------------------------------------
+int gprc_sym_eigen(gprc_ctx* ctx, const double* A, int64_t lda, int64_t m, double* values_out, double* vectors_out, int* sweeps_out) {
+  GPRC_TRY(use_device(ctx));
+  if (!A || !values_out || m < 1 || lda < m) { set_error("sym_eigen: bad arguments"); return GPRC_ERR_ARG; }
+  hipStream_t s = ctx->stream;
+  In a;
+  Out vals, vecs;
+  GPRC_TRY(a.set(s, A, lda * m));
+  GPRC_TRY(vals.set(values_out, m));
+  if (vectors_out) GPRC_TRY(vecs.set(vectors_out, m * m));
+  DevMem V;
+  struct IntMem { int* p = nullptr; ~IntMem() { if (p) (void)hipFree(p); } } permd;
+  GPRC_TRY(V.alloc(m * m));
+  std::vector<double> values;
+  std::vector<int> perm;
+  GPRC_TRY(sym_eigen_dev(ctx, a.dev, lda, m, V.p, values, perm, sweeps_out));
+  std::vector<double> sorted(m);
+  for (int64_t k = 0; k < m; ++k) sorted[k] = values[perm[k]];
+  GPRC_HIP(hipMemcpyAsync(vals.dev, sorted.data(), sizeof(double) * m, hipMemcpyHostToDevice, s));
+  if (vectors_out) {
+    GPRC_HIP(hipMalloc(&permd.p, sizeof(int) * (size_t)m));
+    GPRC_HIP(hipMemcpyAsync(permd.p, perm.data(), sizeof(int) * m, hipMemcpyHostToDevice, s));
+    GPRC_TRY(launch_gather_scale_cols(s, V.p, (int)m, permd.p, nullptr, vecs.dev, m));
+    GPRC_TRY(vecs.finish(s));
+  }
+  GPRC_TRY(vals.finish(s));
+  GPRC_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int gprc_mvn_factor(gprc_ctx* ctx, const double* cov, int64_t ld, int64_t m, double tol, double* L_out, int* method_out) {
+  GPRC_TRY(use_device(ctx));
+  if (!cov || !L_out || m < 1 || ld < m) { set_error("mvn_factor: bad arguments"); return GPRC_ERR_ARG; }
+  hipStream_t s = ctx->stream;
+  In c;
+  Out L;
+  GPRC_TRY(c.set(s, cov, ld * m));
+  GPRC_TRY(L.set(L_out, m * m));
+  int method = 0;
+  GPRC_TRY(mvn_factor_dev(ctx, c.dev, ld, m, tol, L.dev, &method));
+  GPRC_TRY(L.finish(s));
+  GPRC_HIP(hipStreamSynchronize(s));
+  if (method_out) *method_out = method;
+  return 0;
+}
+
+int gprc_mvn_sample(gprc_ctx* ctx, const double* cov, int64_t ld, int64_t m, const double* mean, double tol, const double* Z,
+                    int64_t n_draws, double* out, int* method_out) {
+  GPRC_TRY(use_device(ctx));
+  if (!cov || !mean || !Z || !out || m < 1 || ld < m || n_draws < 1) { set_error("mvn_sample: bad arguments"); return GPRC_ERR_ARG; }
+  hipStream_t s = ctx->stream;
+  In c, mu, z;
+  Out o;
+  GPRC_TRY(c.set(s, cov, ld * m));
+  GPRC_TRY(mu.set(s, mean, m));
+  GPRC_TRY(z.set(s, Z, m * n_draws));
+  GPRC_TRY(o.set(out, m * n_draws));
+  DevMem L;
+  GPRC_TRY(L.alloc(m * m));
+  int method = 0;
+  GPRC_TRY(mvn_factor_dev(ctx, c.dev, ld, m, tol, L.p, &method));
+  GPRC_TRY(launch_affine_lz(s, L.p, m, m, mu.dev, z.dev, m, n_draws, o.dev, m, method == 1));  // drop(mean) + L %*% Z  :369
+  GPRC_TRY(o.finish(s));
+  GPRC_HIP(hipStreamSynchronize(s));
+  if (method_out) *method_out = method;
+  return 0;
 }
 
 int gprc_prof_enable(int on) {

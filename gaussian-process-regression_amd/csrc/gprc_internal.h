@@ -42,7 +42,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 // ---- in-library event profiler (bench.py's live roofline numbers) ---------------------------------
 enum ProfKind { PK_FILL = 0, PK_POTF2 = 1, PK_TRSM_PANEL = 2, PK_GEMM_INNER = 3, PK_TRAILING = 4, PK_SOLVE_UPDATE = 5,
-                PK_TRSV = 6, PK_ROWREDUCE = 7, PK_COV_SYRK = 8, PK_DERIV = 9, PK_COUNT = 10 };
+                PK_TRSV = 6, PK_ROWREDUCE = 7, PK_COV_SYRK = 8, PK_DERIV = 9, PK_JACOBI = 10, PK_COUNT = 11 };
 bool prof_enabled();
 void prof_begin(hipStream_t s, int kind);
 void prof_end(hipStream_t s, int kind, double flops, double bytes);
@@ -108,6 +108,14 @@ int launch_gpc_build_B(hipStream_t s, const double* Kfull, int64_t n_pad, const 
 int launch_gpc_grad(hipStream_t s, const double* f, const double* y, int64_t n, double* g, double* sw);           // g=(y+1)/2-P
 int launch_scale_cols(hipStream_t s, double* vt, int64_t ld, int64_t rows, int64_t cols, const double* colscale); // vt[i,j]*=colscale[j]
 int launch_gpc_class_prob(hipStream_t s, const double* fs, const double* vf, double* out, int64_t n);              // R/GPCclass.R:116-117
+// sampling support (kernels_eig.hip)
+int launch_pack_dense(hipStream_t s, const double* A, int64_t lda, int64_t m, int64_t n_pad, double* packed);
+int launch_sym_copy(hipStream_t s, const double* A, int64_t lda, int64_t m, double* W, double* V);
+int launch_jacobi_sweep(hipStream_t s, double* W, double* V, int m, double* cs);
+int launch_jacobi_offnorm(hipStream_t s, const double* W, int m, double* off, double* dg);
+int launch_gather_scale_cols(hipStream_t s, const double* V, int m, const int* perm, const double* scale, double* out, int64_t ldo);
+int launch_affine_lz(hipStream_t s, const double* L, int64_t ldl, int64_t m, const double* mean, const double* Z, int64_t ldz,
+                     int64_t ndraws, double* out, int64_t ldo, int lower);
 int launch_diag_sum(hipStream_t s, const double* packed, int64_t n_pad, int64_t n, double* out);                  // sum(diag(L))
 
 }  // namespace gprc

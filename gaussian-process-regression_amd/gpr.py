@@ -107,6 +107,33 @@ class GPR:
         nat.check(nat.lib().gprc_gpr_predict(self._model, Xs.ctypes.data, ns, 0, mean.ctypes.data, cov.ctypes.data))
         return [mean.reshape(-1, 1), cov]                                                    # :168
 
+    def posterior_draws(self, n=5, limits=None, length_out=200, *, z=None, rng=None):
+        """The data behind GPR$plot_posterior_draws(n = 5, limits = expand_range(X), length.out = 200)  --
+        R/GPRclass.R:190-199 (one-dimensional inputs only, :192-195): test points, cbind(mean, diag(cov)) and n draws
+        from the posterior, multivariate_normal(n, mean, cov).  Returns dict(x, y (length.out x 2), z (length.out x n)).
+        The ggplot layer itself is not part of this package."""
+        from .sampling import expand_range, multivariate_normal
+        if self._X.shape[0] > 1:
+            raise ValueError("No plot method for multidimensional data.")                    # :192-193
+        lo, hi = expand_range(self._X) if limits is None else (float(limits[0]), float(limits[1]))
+        testpoints = np.linspace(lo, hi, int(length_out))                                    # seq(..., length.out)
+        mean, cov = self.predict(testpoints, pointwise_var=False)                            # :197
+        y = np.column_stack([mean[:, 0], np.diag(cov)])                                      # :198
+        zz = multivariate_normal(n, mean[:, 0], cov, z=z, rng=rng)                           # :199
+        return {"x": testpoints, "y": y, "z": zz}
+
+    def posterior_variance(self, where, limits=None, length_out=200):
+        """The data behind GPR$plot_posterior_variance(where, limits, length.out)  --  R/GPRclass.R:211-221: posterior
+        covariance between each test point and each point of `where`.  Returns dict(x, y (length.out x length(where)))."""
+        from .sampling import expand_range
+        if self._X.shape[0] > 1:
+            raise ValueError("No plot method for multidimensional data.")
+        where = np.atleast_1d(np.asarray(where, dtype=np.float64))
+        lo, hi = expand_range(self._X) if limits is None else (float(limits[0]), float(limits[1]))
+        testpoints = np.linspace(lo, hi, int(length_out))
+        cov = self.predict(np.concatenate([where, testpoints]), pointwise_var=False)[1]
+        return {"x": testpoints, "y": cov[where.size:, :where.size]}                         # [(len + 1):(len + length(testpoints)), 1:len]
+
     def _get_L(self):
         if self._L is None:  # lazy: n x n doubles cross PCIe only when `$L` is read
             n = self._X.shape[1]

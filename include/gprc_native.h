@@ -205,6 +205,23 @@ GPRC_API int gprc_gpr_model_from_device(gprc_ctx* ctx, int kernel, const double*
 GPRC_API int gprc_dev_solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt,
                         int64_t ld, int64_t m_pad);
 
+/* ---- sampling: multivariate_normal(n, mean, covariance, tol = 1e-6)  (R/GPRclass.R:360-370) --------------------------
+ * L = t(chol(covariance)); if the Cholesky fails (the usual case for a posterior covariance K(X*,X*) - t(v) %*% v,
+ * which is numerically rank deficient) L = eigen$vectors %*% diag(sqrt(pmax(eigen$values, 0))) after
+ * stopifnot(all(eigen$values > -tol * abs(eigen$values[1]))) -> GPRC_ERR_NOT_PD.  The standard normal matrix Z
+ * (m x n_draws, column-major) comes from the caller: R draws it with rnorm on the host and so does the binding, so
+ * the generator stays the caller's.  out = drop(mean) + L %*% Z, m x n_draws.  *method_out: 1 Cholesky, 2 eigen.
+ * Eigenvectors are defined up to sign (and basis within repeated eigenvalues); with the eigen branch the draws for a
+ * given Z therefore differ between LAPACK builds, this library and R, while L %*% t(L) -- the distribution -- agrees. */
+GPRC_API int gprc_mvn_factor(gprc_ctx* ctx, const double* cov, int64_t ld, int64_t m, double tol, double* L_out, int* method_out);
+GPRC_API int gprc_mvn_sample(gprc_ctx* ctx, const double* cov, int64_t ld, int64_t m, const double* mean, double tol, const double* Z,
+                    int64_t n_draws, double* out, int* method_out);
+/* eigen(A, symmetric = TRUE): eigenvalues in decreasing order and orthonormal eigenvectors (columns, m x m, may be
+ * NULL); only the lower triangle of A is read (LAPACK dsyevr 'L', as R calls it).  Cyclic two-sided Jacobi with a
+ * round-robin pair order on the device, m <= 16384; *sweeps_out = sweeps used. */
+GPRC_API int gprc_sym_eigen(gprc_ctx* ctx, const double* A, int64_t lda, int64_t m, double* values_out, double* vectors_out,
+                   int* sweeps_out);
+
 /* ---- measurement: per-kernel-kind HIP-event timing (bench.py's live roofline numbers) ------------ *
  * When enabled, every launch is bracketed by two hipEvents on the stream it is launched on.  Kinds:
  * 0 fill, 1 potf2_inv, 2 trsm_panel, 3 in-panel GEMM (K=128), 4 trailing update, 5 predict right

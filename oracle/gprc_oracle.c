@@ -624,3 +624,103 @@ ORACLE_API int oracle_fit_gradient(int id, const double* par, int npar, const do
   free(K); free(Kd); free(Kinv); free(alpha);
   return rc;
 }
+
+/* ================================================================================================
+ * multivariate_normal (R/GPRclass.R:360-370) and the eigen() it falls back to.
+ * ============================================================================================== */
+
+/* eigen(A, symmetric = TRUE): classical row-cyclic Jacobi (Golub & Van Loan, Alg. 8.4.3); the lower triangle of A is
+ * read.  values: decreasing; vectors: m x m, columns orthonormal (signs arbitrary, as LAPACK's are).  Returns sweeps. */
+ORACLE_API int oracle_sym_eigen(const double* A, int64_t m, int64_t lda, double* values, double* vectors) {
+  double* W = (double*)malloc(sizeof(double) * (size_t)(m * m));
+  double* V = (double*)malloc(sizeof(double) * (size_t)(m * m));
+  int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)m);
+  if (!W || !V || !idx) { free(W); free(V); free(idx); return -1; }
+  for (int64_t j = 0; j < m; ++j)
+    for (int64_t i = 0; i < m; ++i) {
+      W[i + j * m] = (i >= j) ? A[i + j * lda] : A[j + i * lda];
+      V[i + j * m] = (i == j) ? 1.0 : 0.0;
+    }
+  int sweeps = 0;
+  for (; sweeps < 60; ++sweeps) {
+    ldbl off = 0.0L, tot = 0.0L;
+    for (int64_t j = 0; j < m; ++j)
+      for (int64_t i = 0; i < m; ++i) {
+        ldbl v = (ldbl)W[i + j * m] * W[i + j * m];
+        tot += v;
+        if (i != j) off += v;
+      }
+    ldbl rel = (ldbl)m * 2.220446049250313e-16L; /* ||off||_F <= max(1e-15, m eps) ||A||_F: the rounding floor */
+    if (rel < 1e-15L) rel = 1e-15L;
+    if (off <= rel * rel * tot) break;
+    for (int64_t p = 0; p < m - 1; ++p)
+      for (int64_t q = p + 1; q < m; ++q) {
+        double apq = W[p + q * m];
+        if (apq == 0.0) continue;
+        double tau = (W[q + q * m] - W[p + p * m]) / (2.0 * apq);
+        double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+        double c = 1.0 / sqrt(1.0 + t * t), sn = t * c;
+        for (int64_t i = 0; i < m; ++i) { /* W <- W J, V <- V J */
+          double a = W[i + p * m], b = W[i + q * m];
+          W[i + p * m] = c * a - sn * b;
+          W[i + q * m] = sn * a + c * b;
+          a = V[i + p * m]; b = V[i + q * m];
+          V[i + p * m] = c * a - sn * b;
+          V[i + q * m] = sn * a + c * b;
+        }
+        for (int64_t j = 0; j < m; ++j) { /* W <- J^T W */
+          double a = W[p + j * m], b = W[q + j * m];
+          W[p + j * m] = c * a - sn * b;
+          W[q + j * m] = sn * a + c * b;
+        }
+      }
+  }
+  for (int64_t i = 0; i < m; ++i) idx[i] = i;
+  for (int64_t i = 1; i < m; ++i) { /* stable insertion sort, decreasing */
+    int64_t k = idx[i], j = i;
+    while (j > 0 && W[idx[j - 1] + idx[j - 1] * m] < W[k + k * m]) { idx[j] = idx[j - 1]; --j; }
+    idx[j] = k;
+  }
+  for (int64_t k = 0; k < m; ++k) {
+    values[k] = W[idx[k] + idx[k] * m];
+    if (vectors)
+      for (int64_t i = 0; i < m; ++i) vectors[i + k * m] = V[i + idx[k] * m];
+  }
+  free(W); free(V); free(idx);
+  return sweeps;
+}
+
+/* L of multivariate_normal: t(chol(covariance)) (:362) or the eigen fallback (:363-368).  L: m x m.
+ * Returns 1 (Cholesky), 2 (eigen), -4 (stopifnot(all(eigval > -tol * abs(eigval[1]))) failed), -1 (memory). */
+ORACLE_API int oracle_mvn_factor(const double* cov, int64_t m, int64_t ld, double tol, double* L) {
+  for (int64_t j = 0; j < m; ++j)
+    for (int64_t i = 0; i < m; ++i) L[i + j * m] = (i >= j) ? cov[i + j * ld] : 0.0;
+  if (oracle_potrf_lower(L, m, m) == 0) {
+    zero_upper(L, m);
+    return 1;
+  }
+  double* val = (double*)malloc(sizeof(double) * (size_t)m);
+  double* vec = (double*)malloc(sizeof(double) * (size_t)(m * m));
+  if (!val || !vec) { free(val); free(vec); return -1; }
+  int rc = 2;
+  if (oracle_sym_eigen(cov, m, ld, val, vec) < 0) rc = -1;
+  for (int64_t k = 0; rc == 2 && k < m; ++k)
+    if (!(val[k] > -tol * fabs(val[0]))) rc = -4;
+  if (rc == 2)
+    for (int64_t k = 0; k < m; ++k) {
+      double sc = sqrt(val[k] > 0.0 ? val[k] : 0.0); /* sqrt(pmax(eigval, 0)) */
+      for (int64_t i = 0; i < m; ++i) L[i + k * m] = vec[i + k * m] * sc;
+    }
+  free(val); free(vec);
+  return rc;
+}
+
+/* drop(mean) + L %*% Z   (:369); Z, out: m x n */
+ORACLE_API void oracle_affine_lz(const double* L, int64_t m, const double* mean, const double* Z, int64_t n, double* out) {
+  for (int64_t j = 0; j < n; ++j)
+    for (int64_t i = 0; i < m; ++i) {
+      double s = 0.0;
+      for (int64_t k = 0; k < m; ++k) s += L[i + k * m] * Z[k + j * m];
+      out[i + j * m] = mean[i] + s;
+    }
+}

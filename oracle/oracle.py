@@ -218,3 +218,42 @@ def fit_gradient(kid, params, X, y):
     if rc:
         raise ValueError(f"oracle_fit_gradient rc={rc}")
     return g
+
+
+def sym_eigen(A):
+    """eigen(A, symmetric = TRUE): (values decreasing, vectors as columns); reads the lower triangle."""
+    A = _f(A)
+    m = A.shape[0]
+    val = np.empty(m)
+    vec = np.empty((m, m), order="F")
+    fn = lib().oracle_sym_eigen
+    fn.restype = C.c_int
+    if fn(_p(A), _i64(m), _i64(m), _p(val), _p(vec)) < 0:
+        raise MemoryError("oracle_sym_eigen")
+    return val, vec
+
+
+def mvn_factor(cov, tol=1e-6):
+    """(L, method) of multivariate_normal (R/GPRclass.R:362-368); method 1 = Cholesky, 2 = eigen."""
+    cov = _f(cov)
+    m = cov.shape[0]
+    L = np.empty((m, m), order="F")
+    fn = lib().oracle_mvn_factor
+    fn.restype = C.c_int
+    rc = fn(_p(cov), _i64(m), _i64(m), C.c_double(tol), _p(L))
+    if rc == -4:
+        raise ArithmeticError("all(eigval > -tol * abs(eigval[1])) is not TRUE")
+    if rc < 0:
+        raise MemoryError("oracle_mvn_factor")
+    return L, rc
+
+
+def multivariate_normal(mean, cov, Z, tol=1e-6):
+    """drop(mean) + L %*% Z for a given standard normal matrix Z (m x n)."""
+    L, method = mvn_factor(cov, tol)
+    m = L.shape[0]
+    Z = _f(np.asarray(Z, dtype=np.float64).reshape(m, -1))
+    mean = np.ascontiguousarray(np.asarray(mean, dtype=np.float64).ravel())
+    out = np.empty(Z.shape, order="F")
+    lib().oracle_affine_lz(_p(L), _i64(m), _p(mean), _p(Z), _i64(Z.shape[1]), _p(out))
+    return out, method

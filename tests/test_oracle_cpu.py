@@ -186,3 +186,29 @@ def test_fit_gradient_restatement_against_literal_numpy():
     # gammaexp: -exp(.) * (r/l)^gamma * log(r/l) is 0 * -Inf = NaN at r = 0, i.e. on every diagonal entry (R/fit.R:12)
     g = orc.fit_gradient(orc.GAMMAEXP, [1.0, 1.0], rng.uniform(-3, 3, (2, 10)), rng.normal(size=10))
     assert math.isnan(g[0]) and math.isfinite(g[1])
+
+
+def test_sampling_restatement():
+    """oracle_sym_eigen / oracle_mvn_factor (R/GPRclass.R:360-370) against numpy's LAPACK: eigenvalues, the
+    reconstruction, L L^T = covariance on both branches, and the acceptance rule :366."""
+    rng = np.random.default_rng(12)
+    for m, r in [(1, 1), (2, 2), (31, 7), (64, 64)]:
+        B = rng.normal(size=(m, r))
+        A = B @ B.T
+        val, vec = orc.sym_eigen(A)
+        w = np.linalg.eigvalsh(A)[::-1]
+        assert np.max(np.abs(val - w)) <= 1e-12 * max(w[0], 1e-300)
+        assert np.max(np.abs(vec @ np.diag(val) @ vec.T - A)) <= 1e-12 * w[0] and np.max(np.abs(vec.T @ vec - np.eye(m))) <= 1e-12
+        L, method = orc.mvn_factor(A)
+        assert method == (1 if r == m else 2)
+        assert np.max(np.abs(L @ L.T - A)) <= 1e-12 * w[0]
+        if method == 1:
+            assert np.max(np.abs(L - np.linalg.cholesky(A))) <= 1e-12 * math.sqrt(w[0]) and np.all(np.triu(L, 1) == 0)
+    A = np.diag([2.0, 1.0, -1e-3])                         # eigenvalue below -tol * |largest|: stopifnot fails
+    with pytest.raises(ArithmeticError):
+        orc.mvn_factor(A, 1e-6)
+    L, method = orc.mvn_factor(np.diag([2.0, 1.0, -1e-9]), 1e-6)   # within tol: clipped to zero (pmax)
+    assert method == 2 and np.max(np.abs(L @ L.T - np.diag([2.0, 1.0, 0.0]))) <= 1e-15
+    Z = rng.normal(size=(3, 4))
+    out, _ = orc.multivariate_normal([1.0, 2.0, 3.0], np.diag([4.0, 9.0, 16.0]), Z)
+    assert np.allclose(out, np.array([[1.0], [2.0], [3.0]]) + np.diag([2.0, 3.0, 4.0]) @ Z, rtol=0, atol=1e-15)
