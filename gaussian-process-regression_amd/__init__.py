@@ -14,8 +14,10 @@ from .gpr import (GPR, GPR_constant, GPR_linear, GPR_polynomial, GPR_sqrexp, GPR
 from .gpc import GPC
 from .fit import fit, dens, dens_deriv
 from .sampling import multivariate_normal, expand_range, mvn_factor, sym_eigen
+from .simulation import combine_all, iid_noise, simulate_regression, simulate_regression_gp, simulate_classification
 
-__all__ = ["fit", "dens", "dens_deriv", "multivariate_normal", "expand_range", "mvn_factor", "sym_eigen", "GPR", "GPR_constant", "GPR_linear", "GPR_polynomial", "GPR_sqrexp", "GPR_gammaexp",
+__all__ = ["fit", "dens", "dens_deriv", "multivariate_normal", "expand_range", "mvn_factor", "sym_eigen", "combine_all", "iid_noise",
+           "simulate_regression", "simulate_regression_gp", "simulate_classification", "GPR", "GPR_constant", "GPR_linear", "GPR_polynomial", "GPR_sqrexp", "GPR_gammaexp",
            "GPR_rationalquadratic", "GPC", "cov_func", "covariance_matrix", "constant", "linear", "polynomial",
            "sqrexp", "gammaexp", "rationalquadratic", "CovFunc", "GprcError", "NotPositiveDefinite", "Context",
            "default_context", "device_count"]

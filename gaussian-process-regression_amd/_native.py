@@ -94,6 +94,7 @@ PROTOTYPES = {
     "gprc_mvn_factor": (C.c_int, [_vp, _vp, _i64, _i64, C.c_double, _vp, C.POINTER(C.c_int)]),
     "gprc_mvn_sample": (C.c_int, [_vp, _vp, _i64, _i64, _vp, C.c_double, _vp, _i64, _vp, C.POINTER(C.c_int)]),
     "gprc_sym_eigen": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, C.POINTER(C.c_int)]),
+    "gprc_combine_all": (C.c_int, [_vp, _vp, C.POINTER(_i64), C.c_int, _vp]),
     "gprc_prof_enable": (C.c_int, [C.c_int]),
     "gprc_prof_reset": (C.c_int, []),
     "gprc_prof_kinds": (C.c_int, []),

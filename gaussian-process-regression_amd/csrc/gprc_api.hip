@@ -1032,6 +1032,28 @@ int gprc_mvn_sample(gprc_ctx* ctx, const double* cov, int64_t ld, int64_t m, con
   return 0;
 }
 
+// combine_all(lst)  --  R/simulation.R:338-349 (the test grid of the simulate_* harness, :101-102)
+int gprc_combine_all(gprc_ctx* ctx, const double* axis_values, const int64_t* lengths, int d, double* out) {
+  GPRC_TRY(use_device(ctx));
+  if (!axis_values || !lengths || !out || d < 1 || d > 64) { set_error("combine_all: bad arguments"); return GPRC_ERR_ARG; }
+  int64_t sum = 0, total = 1;
+  for (int k = 0; k < d; ++k) {
+    if (lengths[k] < 1) { set_error("combine_all: every axis needs at least one value"); return GPRC_ERR_ARG; }
+    sum += lengths[k];
+    if (total > ((int64_t)1 << 40) / lengths[k]) { set_error("combine_all: grid too large"); return GPRC_ERR_ARG; }
+    total *= lengths[k];
+  }
+  hipStream_t s = ctx->stream;
+  In v;
+  Out o;
+  GPRC_TRY(v.set(s, axis_values, sum));
+  GPRC_TRY(o.set(out, total * d));
+  GPRC_TRY(launch_combine_all(s, v.dev, lengths, d, o.dev));
+  GPRC_TRY(o.finish(s));
+  GPRC_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 int gprc_prof_enable(int on) {
   g_prof_on = on != 0;
   return 0;

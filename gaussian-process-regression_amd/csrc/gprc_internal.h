@@ -116,6 +116,7 @@ int launch_jacobi_offnorm(hipStream_t s, const double* W, int m, double* off, do
 int launch_gather_scale_cols(hipStream_t s, const double* V, int m, const int* perm, const double* scale, double* out, int64_t ldo);
 int launch_affine_lz(hipStream_t s, const double* L, int64_t ldl, int64_t m, const double* mean, const double* Z, int64_t ldz,
                      int64_t ndraws, double* out, int64_t ldo, int lower);
+int launch_combine_all(hipStream_t s, const double* vals_dev, const int64_t* lengths, int d, double* out);
 int launch_diag_sum(hipStream_t s, const double* packed, int64_t n_pad, int64_t n, double* out);                  // sum(diag(L))
 
 }  // namespace gprc

@@ -145,6 +145,16 @@ __global__ __launch_bounds__(256) void affine_lz_kernel(const double* L, int64_t
   for (int j = 0; j < ND; ++j) out[i + j * ldo] = mean[i] + acc[j];
 }
 
+// combine_all(lst) of R/simulation.R:338-349: every combination of the axis values, one point per column, the LAST
+// axis varying fastest: out[k, c] = lst[[k]][(c / each_k) % len_k], each_k = prod_{j > k} len_j.  Axis values are
+// concatenated in `vals`; `offs[k]` is where axis k starts.  d <= 64 (kernel argument struct).
+struct GridSpec { int d; int64_t len[64], each[64], offs[64]; };
+__global__ __launch_bounds__(256) void combine_all_kernel(GridSpec g, const double* vals, int64_t total, double* out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= total) return;
+  for (int k = 0; k < g.d; ++k) out[c * g.d + k] = vals[g.offs[k] + (c / g.each[k]) % g.len[k]];
+}
+
 inline unsigned blocks(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
 }  // namespace
@@ -200,6 +210,19 @@ int launch_affine_lz(hipStream_t s, const double* L, int64_t ldl, int64_t m, con
     hipLaunchKernelGGL((affine_lz_kernel<8>), grid, block, 0, s, L, ldl, m, mean, Z + j * ldz, ldz, out + j * ldo, ldo, lower);
   for (; j < ndraws; ++j)
     hipLaunchKernelGGL((affine_lz_kernel<1>), grid, block, 0, s, L, ldl, m, mean, Z + j * ldz, ldz, out + j * ldo, ldo, lower);
+  GPRC_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_combine_all(hipStream_t s, const double* vals_dev, const int64_t* lengths, int d, double* out) {
+  if (d < 1 || d > 64) { set_error("combine_all: 1 <= number of axes <= 64"); return GPRC_ERR_ARG; }
+  GridSpec g{};
+  g.d = d;
+  int64_t off = 0, each = 1;
+  for (int k = 0; k < d; ++k) { g.len[k] = lengths[k]; g.offs[k] = off; off += lengths[k]; }
+  for (int k = d - 1; k >= 0; --k) { g.each[k] = each; each *= lengths[k]; }
+  if (each <= 0) return 0;
+  hipLaunchKernelGGL(combine_all_kernel, dim3(blocks(each, 256)), dim3(256), 0, s, g, vals_dev, each, out);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

@@ -222,6 +222,10 @@ GPRC_API int gprc_mvn_sample(gprc_ctx* ctx, const double* cov, int64_t ld, int64
 GPRC_API int gprc_sym_eigen(gprc_ctx* ctx, const double* A, int64_t lda, int64_t m, double* values_out, double* vectors_out,
                    int* sweeps_out);
 
+/* combine_all(lst) (R/simulation.R:338-349), the test grid of the simulate_* harness (:101-102, :223-224): all
+ * combinations of the axis values, one point per column (d x prod(lengths), column-major), the LAST axis varying
+ * fastest.  axis_values: the axes concatenated (sum(lengths) doubles); lengths: d host integers; d <= 64. */
+GPRC_API int gprc_combine_all(gprc_ctx* ctx, const double* axis_values, const int64_t* lengths, int d, double* out);
 /* ---- measurement: per-kernel-kind HIP-event timing (bench.py's live roofline numbers) ------------ *
  * When enabled, every launch is bracketed by two hipEvents on the stream it is launched on.  Kinds:
  * 0 fill, 1 potf2_inv, 2 trsm_panel, 3 in-panel GEMM (K=128), 4 trailing update, 5 predict right

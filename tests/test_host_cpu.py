@@ -199,3 +199,23 @@ def test_optim_until_error_bfgs_semantics():
         raise ArithmeticError("not positive definite")
     par, val = _optim_bfgs_until_error((1.0, 1.0), f_fails, gr_fails)      # nothing recorded: (start, sentinel)
     assert par == (1.0, 1.0) and val == SENTINEL
+
+
+def test_simulation_host_pieces():
+    """The host-side pieces of the simulate_* harness (R/simulation.R): summary(), limits handling, apply(., 2, f),
+    iid_noise, the fractional length.out rule of the test grid."""
+    from gprc_amd.simulation import Summary, _apply_cols, _limits, iid_noise
+    s = Summary.of([1, 2, 3, 4, 10])                                       # R: summary(c(1, 2, 3, 4, 10))
+    assert s == {"Min.": 1.0, "1st Qu.": 2.0, "Median": 3.0, "Mean": 4.0, "3rd Qu.": 4.0, "Max.": 10.0}
+    assert Summary.of([0.5, 1.5, 4.0, 2.5])["1st Qu."] == 1.25            # quantile type 7
+    assert _limits([-1, 1, -2, 2]).tolist() == [[-1, 1], [-2, 2]]          # matrix(limits, ncol = 2, byrow = TRUE)
+    with pytest.raises(ValueError):
+        _limits([1, 2, 3])
+    M = np.array([[1.0, 2.0], [3.0, 4.0]])
+    assert _apply_cols(M, lambda x: np.sum(x) ** 2).tolist() == [16.0, 36.0]
+    assert _apply_cols(M[:1], lambda x: 0.1 * x ** 3).tolist() == [0.1 * 1.0 ** 3, 0.1 * 2.0 ** 3]
+    noise = iid_noise(lambda n, sd: np.full(n, sd), sd=0.25)              # iid_noise(rnorm, sd = ...) shape contract
+    assert noise(np.zeros((3, 7))).tolist() == [0.25] * 7
+    if not gpu_available():
+        with pytest.raises(GprcError, match="no CPU fallback"):
+            gprc_amd.combine_all([[0.0, 1.0], [2.0, 3.0]])
