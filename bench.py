@@ -136,6 +136,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         comm = TorchComm()
+        # panel broadcast: RCCL's rooted broadcast vs scatter + all-gather, timed once on this node (GPRC_BCAST pins it)
+        comm.calibrate(lambda c: torch.empty(c, dtype=torch.float64, device="cuda"), torch.cuda.synchronize)
     else:
         comm = SingleComm()
     if args.gpus != world and rank == 0:
@@ -262,6 +264,7 @@ def main():
                           "predict_P1_P3": round(sum(b.elapsed_time(c) for _, b, c in marks) / len(marks), 3)},
             "kernels": kernels,
             "frac_of_fp64_peak_end_to_end": round(flops / (elapsed / args.steps) * 1e-12 / (FP64_MFMA_PEAK_TFLOPS * world), 4),
+            "panel_broadcast": getattr(comm, "calibration", None) or {"choice": getattr(comm, "choice", None)},
             "parity_gate_normwise_err": gate_err,
             "outputs_sane": sane,
         }

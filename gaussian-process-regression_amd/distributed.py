@@ -67,15 +67,82 @@ class SingleComm:
 
 
 class TorchComm:
-    """torch.distributed (backend nccl == RCCL on ROCm; gloo on CPU)."""
+    """torch.distributed (backend nccl == RCCL on ROCm; gloo on CPU).
 
-    def __init__(self):
+    Panel broadcast strategy.  xGMI is point-to-point: a rooted broadcast that pipelines through a ring moves the
+    panel at ONE link's rate, while the root has 7 links.  `scatter_allgather` has the root scatter 1/G of the panel
+    to every peer (G-1 links in parallel) and then all-gathers the pieces (every link carries 1/G), the classic
+    large-message broadcast.  Which one wins depends on what RCCL's own broadcast does on the node at hand, so
+    `calibrate()` times both on a panel-sized buffer once and all ranks adopt the faster (GPRC_BCAST=broadcast |
+    scatter_allgather pins it).  Results are identical either way (pure data movement)."""
+
+    def __init__(self, strategy=None):
         import torch.distributed as dist
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.strategy = strategy or os.environ.get("GPRC_BCAST", "auto")
+        if self.strategy not in ("auto", "broadcast", "scatter_allgather"):
+            raise ValueError("GPRC_BCAST must be auto, broadcast or scatter_allgather")
+        self.choice = "broadcast" if self.strategy == "auto" else self.strategy   # until calibrate() decides
+        self.calibration = None
+
+    MIN_SPLIT = 1 << 17   # doubles (1 MiB): below this two collectives cost more latency than they save
 
     def broadcast(self, t, src):
-        self.dist.broadcast(t, src=src)
+        if (self.choice == "scatter_allgather" and self.world > 1 and t.numel() % self.world == 0
+                and t.numel() >= self.MIN_SPLIT and t.is_contiguous()):
+            self._scatter_allgather(t, src)
+        else:
+            self.dist.broadcast(t, src=src)
+
+    def _scatter_allgather(self, t, src):
+        c = t.numel() // self.world
+        mine = t[self.rank * c:(self.rank + 1) * c]
+        if self.rank == src:
+            self.dist.scatter(mine, scatter_list=[t[r * c:(r + 1) * c] for r in range(self.world)], src=src)
+        else:
+            self.dist.scatter(mine, src=src)
+        self.dist.all_gather_into_tensor(t, mine)   # in place: `mine` is this rank's slice of t
+
+    def calibrate(self, make_buffer, sync, count=1 << 24, reps=3):
+        """Times both strategies on a `count`-double buffer (make_buffer(count) -> tensor; sync() waits for the
+        device), checks that they deliver the same data, and fixes `self.choice` identically on every rank."""
+        import time
+        import torch
+        if self.world == 1 or self.strategy != "auto":
+            return self.choice
+        count -= count % self.world
+        buf = make_buffer(count)
+        ref = make_buffer(count)
+        times, ok = {}, True
+        for mode in ("broadcast", "scatter_allgather"):
+            self.choice = mode
+            try:
+                for it in range(reps + 1):
+                    if it == 1:
+                        sync(); self.dist.barrier(); t0 = time.perf_counter()
+                    src = it % self.world
+                    if self.rank == src:
+                        buf.copy_(torch.arange(count, dtype=buf.dtype, device=buf.device) * (it + 1))
+                    else:
+                        buf.zero_()
+                    self.broadcast(buf, src)
+                sync()
+                times[mode] = (time.perf_counter() - t0) / reps
+                if mode == "broadcast":
+                    ref.copy_(buf)
+                else:
+                    ok = bool(torch.equal(ref, buf))
+            except RuntimeError:
+                ok = False
+                times[mode] = float("inf")
+        stat = torch.tensor([times["broadcast"], times["scatter_allgather"], 0.0 if ok else 1.0], dtype=torch.float64, device=buf.device)
+        self.dist.all_reduce(stat, op=self.dist.ReduceOp.MAX)      # slowest rank decides; any mismatch vetoes
+        tb, ts, bad = (float(x) for x in stat.cpu())
+        self.choice = "scatter_allgather" if (bad == 0.0 and ts < 0.9 * tb) else "broadcast"
+        self.calibration = {"broadcast_ms": round(tb * 1e3, 3), "scatter_allgather_ms": round(ts * 1e3, 3) if ts != float("inf") else None,
+                            "doubles": count, "agree": bad == 0.0, "choice": self.choice}
+        return self.choice
 
     def min_positive(self, value: int) -> int:
         import torch

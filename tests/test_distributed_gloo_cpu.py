@@ -34,7 +34,7 @@ def _problem(n, d, ns, seed=11):
     return X, y, Xs
 
 
-def _worker(rank, world, port, n, d, ns, out_dir):
+def _worker(rank, world, port, n, d, ns, out_dir, bcast="broadcast"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -46,7 +46,10 @@ def _worker(rank, world, port, n, d, ns, out_dir):
     try:
         X, y, Xs = _problem(n, d, ns)
         ops = OracleOps(orc.SQREXP, [1.0], d, n, 0.1)
-        comm = TorchComm()
+        comm = TorchComm(strategy=bcast)
+        if bcast == "auto":                                  # the timing is arbitrary on CPU: only the protocol is checked
+            comm.calibrate(lambda c: torch.zeros(c, dtype=torch.float64), lambda: None, count=1 << 18, reps=1)
+            assert comm.calibration["agree"] and comm.choice in ("broadcast", "scatter_allgather")
         eng = DistributedGPR(ops, comm)
         g = ops.geom
         ypad = np.zeros(g.n_pad)
@@ -66,12 +69,15 @@ def _worker(rank, world, port, n, d, ns, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 1300), (3, 2100)])
-def test_block_cyclic_fit_and_sliced_predict(tmp_path, world, n):
+@pytest.mark.parametrize("world,n,bcast", [(2, 1300, "broadcast"), (3, 2100, "broadcast"), (2, 1300, "scatter_allgather"),
+                                           (4, 2100, "scatter_allgather"), (2, 1300, "auto")])
+def test_block_cyclic_fit_and_sliced_predict(tmp_path, world, n, bcast):
+    """bcast: how a factored panel reaches the other ranks -- one rooted broadcast, or scatter + all-gather (the
+    large-message form for point-to-point links); "auto" runs the calibration that picks one.  Same results."""
     from oracle import oracle as orc
     d, ns = 3, 37
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, d, ns, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, d, ns, str(tmp_path), bcast), nprocs=world, join=True)
     X, y, Xs = _problem(n, d, ns)
     ref = orc.gpr_fit(orc.SQREXP, [1.0], X.T, y, 0.1)
     mr, vr = orc.gpr_predict(orc.SQREXP, [1.0], X.T, ref["L"], ref["alpha"], Xs.T)
