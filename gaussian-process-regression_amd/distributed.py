@@ -89,7 +89,8 @@ class TorchComm:
     MIN_SPLIT = 1 << 17   # doubles (1 MiB): below this two collectives cost more latency than they save
 
     def broadcast(self, t, src):
-        if (self.choice == "scatter_allgather" and self.world > 1 and t.numel() % self.world == 0
+        pinned = self.strategy == "scatter_allgather"   # pinned: also with one rank, to exercise the two collectives
+        if (self.choice == "scatter_allgather" and (self.world > 1 or pinned) and t.numel() % self.world == 0
                 and t.numel() >= self.MIN_SPLIT and t.is_contiguous()):
             self._scatter_allgather(t, src)
         else:
