@@ -52,6 +52,7 @@ PROTOTYPES = {
     "gprc_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
     "gprc_ctx_destroy": (C.c_int, [_vp]),
     "gprc_ctx_synchronize": (C.c_int, [_vp]),
+    "gprc_ctx_trim": (C.c_int, [_vp]),
     "gprc_kernel_matrix": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, _i64, _vp, _i64]),
     "gprc_kernel_colwise": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _vp, _i64, _i64, _vp]),
     "gprc_gpr_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, C.c_double, C.POINTER(_vp)]),

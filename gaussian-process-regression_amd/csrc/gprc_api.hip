@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "gprc_internal.h"
@@ -73,6 +74,13 @@ struct gprc_ctx {
   double* ws[4] = {nullptr, nullptr, nullptr, nullptr};
   int64_t ws_cap[4] = {0, 0, 0, 0};
   int64_t vt_pad = 0;                     // extra doubles in the chunk's leading dimension (keeps it off powers of two)
+  // Free-list of device blocks released by calls on this context (exact-size reuse).  fit() evaluates the same n
+  // dozens to hundreds of times; without it every dens(v) pays seven hipMalloc/hipFree pairs (each hipFree is a
+  // device-wide sync).  Reuse is safe without events: everything on a context runs on its one stream, in order.
+  struct Block { void* p; size_t bytes; };
+  std::vector<Block> pool;
+  size_t pool_bytes = 0;
+  size_t pool_cap = (size_t)16 << 30;     // GPRC_POOL_BYTES; blocks larger than the cap are never kept
 };
 
 enum ModelType { MODEL_GPR = 1, MODEL_GPC = 2 };
@@ -96,6 +104,48 @@ struct gprc_model {
 
 namespace {
 
+thread_local gprc_ctx* g_cur_ctx = nullptr;  // set by use_device(): whose pool the scoped temporaries below use
+
+int pool_alloc(gprc_ctx* ctx, size_t bytes, void** out) {
+  if (bytes == 0) bytes = 8;
+  if (ctx) {
+    for (size_t i = ctx->pool.size(); i-- > 0;)
+      if (ctx->pool[i].bytes == bytes) {
+        *out = ctx->pool[i].p;
+        ctx->pool_bytes -= bytes;
+        ctx->pool.erase(ctx->pool.begin() + (long)i);
+        return 0;
+      }
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess && ctx && !ctx->pool.empty()) {  // give the cached blocks back and retry once
+    (void)hipGetLastError();
+    for (auto& b : ctx->pool) (void)hipFree(b.p);
+    ctx->pool.clear();
+    ctx->pool_bytes = 0;
+    e = hipMalloc(out, bytes);
+  }
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+  return 0;
+}
+void pool_release(gprc_ctx* ctx, void* p, size_t bytes) {
+  if (!p) return;
+  if (bytes == 0) bytes = 8;
+  if (!ctx || bytes > ctx->pool_cap) { (void)hipFree(p); return; }
+  while (!ctx->pool.empty() && ctx->pool_bytes + bytes > ctx->pool_cap) {  // evict the oldest
+    (void)hipFree(ctx->pool.front().p);
+    ctx->pool_bytes -= ctx->pool.front().bytes;
+    ctx->pool.erase(ctx->pool.begin());
+  }
+  ctx->pool.push_back({p, bytes});
+  ctx->pool_bytes += bytes;
+}
+void pool_trim(gprc_ctx* ctx) {
+  for (auto& b : ctx->pool) (void)hipFree(b.p);
+  ctx->pool.clear();
+  ctx->pool_bytes = 0;
+}
+
 bool is_device_ptr(const void* p) {
   if (!p) return false;
   hipPointerAttribute_t attr;
@@ -108,13 +158,17 @@ bool is_device_ptr(const void* p) {
 struct In {
   const double* dev = nullptr;
   double* tmp = nullptr;
-  ~In() { if (tmp) (void)hipFree(tmp); }
+  gprc_ctx* owner = nullptr;
+  size_t bytes = 0;
+  ~In() { if (tmp) pool_release(owner, tmp, bytes); }
   int set(hipStream_t s, const double* p, int64_t count) {
     if (count <= 0) { dev = nullptr; return 0; }
     if (!p) { set_error("null input pointer"); return GPRC_ERR_ARG; }
     if (is_device_ptr(p)) { dev = p; return 0; }
-    GPRC_HIP(hipMalloc(&tmp, sizeof(double) * (size_t)count));
-    GPRC_HIP(hipMemcpyAsync(tmp, p, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s));
+    owner = g_cur_ctx;
+    bytes = sizeof(double) * (size_t)count;
+    GPRC_TRY(pool_alloc(owner, bytes, (void**)&tmp));
+    GPRC_HIP(hipMemcpyAsync(tmp, p, bytes, hipMemcpyHostToDevice, s));
     dev = tmp;
     return 0;
   }
@@ -125,14 +179,16 @@ struct Out {
   double* tmp = nullptr;
   double* host = nullptr;
   int64_t count = 0;
-  ~Out() { if (tmp) (void)hipFree(tmp); }
+  gprc_ctx* owner = nullptr;
+  ~Out() { if (tmp) pool_release(owner, tmp, sizeof(double) * (size_t)count); }
   int set(double* p, int64_t cnt) {
     count = cnt;
     if (cnt <= 0) return 0;
     if (!p) { set_error("null output pointer"); return GPRC_ERR_ARG; }
     if (is_device_ptr(p)) { dev = p; return 0; }
     host = p;
-    GPRC_HIP(hipMalloc(&tmp, sizeof(double) * (size_t)cnt));
+    owner = g_cur_ctx;
+    GPRC_TRY(pool_alloc(owner, sizeof(double) * (size_t)cnt, (void**)&tmp));
     dev = tmp;
     return 0;
   }
@@ -161,11 +217,14 @@ int ws_get(gprc_ctx* ctx, int slot, int64_t count, double** out) {
 
 struct DevMem {  // scoped device allocation
   double* p = nullptr;
-  ~DevMem() { if (p) (void)hipFree(p); }
+  gprc_ctx* owner = nullptr;
+  size_t bytes = 0;
+  ~DevMem() { if (p) pool_release(owner, p, bytes); }
   int alloc(int64_t count) {
     if (count <= 0) count = 1;
-    GPRC_HIP(hipMalloc(&p, sizeof(double) * (size_t)count));
-    return 0;
+    owner = g_cur_ctx;
+    bytes = sizeof(double) * (size_t)count;
+    return pool_alloc(owner, bytes, (void**)&p);
   }
 };
 
@@ -189,6 +248,7 @@ int make_spec(int kernel, const double* params, int n_params, int64_t d, KernelS
 int use_device(const gprc_ctx* ctx) {
   if (!ctx) { set_error("null context"); return GPRC_ERR_ARG; }
   GPRC_HIP(hipSetDevice(ctx->device));
+  g_cur_ctx = const_cast<gprc_ctx*>(ctx);
   return 0;
 }
 
@@ -251,8 +311,12 @@ void free_model(gprc_model* m) {
   if (!m) return;
   if (m->ctx) (void)hipSetDevice(m->ctx->device);
   if (m->borrowed) m->X = m->y = m->packed = m->winv = m->alpha = nullptr;
-  for (double* p : {m->X, m->y, m->packed, m->winv, m->alpha, m->f_hat, m->sw, m->work})
-    if (p) (void)hipFree(p);
+  const int64_t n_pad = m->n_pad;
+  const std::pair<double*, int64_t> parts[] = {{m->X, m->d * m->n}, {m->y, n_pad}, {m->packed, gprc_packed_size(n_pad)},
+                                               {m->winv, gprc_winv_size(n_pad)}, {m->alpha, n_pad}, {m->f_hat, n_pad},
+                                               {m->sw, n_pad}, {m->work, gprc_trsv_work_size(n_pad)}};
+  for (const auto& pr : parts)
+    if (pr.first) pool_release(m->ctx, pr.first, sizeof(double) * (size_t)pr.second);
   delete m;
 }
 
@@ -264,8 +328,7 @@ int alloc_model(gprc_ctx* ctx, int type, const KernelSpec& ks, int64_t n, int64_
   int rc = 0;
   auto A = [&](double** p, int64_t cnt) {
     if (rc) return;
-    hipError_t e = hipMalloc(p, sizeof(double) * (size_t)cnt);
-    if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(model)", __FILE__, __LINE__);
+    rc = pool_alloc(ctx, sizeof(double) * (size_t)cnt, (void**)p);
   };
   A(&m->X, d * n);
   A(&m->y, n_pad);
@@ -453,6 +516,10 @@ int gprc_ctx_create(int device, void* stream, gprc_ctx** ctx_out) {
     const long long v = std::atoll(vp);
     if (v >= 0 && v % 2 == 0) ctx->vt_pad = v;
   }
+  if (const char* pb = std::getenv("GPRC_POOL_BYTES")) {
+    const long long v = std::atoll(pb);
+    if (v >= 0) ctx->pool_cap = (size_t)v;
+  }
   if (const char* cb = std::getenv("GPRC_CHUNK_BYTES")) {
     const long long v = std::atoll(cb);
     if (v > 0) ctx->chunk_bytes = (size_t)v;
@@ -467,6 +534,8 @@ int gprc_ctx_destroy(gprc_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < 4; ++i)
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+  pool_trim(ctx);
+  if (g_cur_ctx == ctx) g_cur_ctx = nullptr;
   if (ctx->info_dev) (void)hipFree(ctx->info_dev);
   if (ctx->scal_dev) (void)hipFree(ctx->scal_dev);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -474,6 +543,14 @@ int gprc_ctx_destroy(gprc_ctx* ctx) {
   return 0;
 }
 
+int gprc_ctx_trim(gprc_ctx* ctx) {
+  GPRC_TRY(use_device(ctx));
+  GPRC_HIP(hipStreamSynchronize(ctx->stream));
+  pool_trim(ctx);
+  for (int i = 0; i < 4; ++i)
+    if (ctx->ws[i]) { (void)hipFree(ctx->ws[i]); ctx->ws[i] = nullptr; ctx->ws_cap[i] = 0; }
+  return 0;
+}
 int gprc_ctx_synchronize(gprc_ctx* ctx) {
   GPRC_TRY(use_device(ctx));
   GPRC_HIP(hipStreamSynchronize(ctx->stream));

@@ -77,6 +77,10 @@ GPRC_API int gprc_device_count(int* count_out);
  * context create and own one. */
 GPRC_API int gprc_ctx_create(int device, void* stream, gprc_ctx** ctx_out);
 GPRC_API int gprc_ctx_destroy(gprc_ctx* ctx);
+/* Gives the device memory a context keeps for reuse back to the driver: the free-list of blocks released by earlier
+ * calls (exact-size reuse; fit() evaluates the same n over and over; capped by GPRC_POOL_BYTES, default 16 GiB, 0 = off)
+ * and the predict workspaces.  Never needed for correctness. */
+GPRC_API int gprc_ctx_trim(gprc_ctx* ctx);
 GPRC_API int gprc_ctx_synchronize(gprc_ctx* ctx);
 
 /* ---- L1: covariance-function layer --------------------------------------------------------- */

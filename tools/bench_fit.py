@@ -35,6 +35,12 @@ t_grad, grad = timed(lambda: g.dens_deriv(X, y, "rationalquadratic", v), 3)
 prof = {k: r for k, r in nat.prof_summary().items() if r["count"]}
 L.gprc_prof_enable(0)
 
+orc.set_threads(1)                               # the CPU lines below are single-thread figures
+# the reference's own regime: X <- seq(-5, 5, by = 0.2) (51 points, d = 1): per-call latency, dominated by launch + PCIe
+Xs_, ys_ = np.arange(-5, 5.0001, 0.2).reshape(1, -1), np.sin(np.arange(-5, 5.0001, 0.2))
+t_small, _ = timed(lambda: g.dens(Xs_, ys_, 0.1, "sqrexp", [1.0]), 50)
+t_small_o, _ = timed(lambda: orc.gpr_fit(orc.SQREXP, [1.0], Xs_, ys_, 0.1)["logp"], 50)
+
 nc = 1024                                        # CPU sample: the oracle's gradient is an unblocked O(n^3) LU
 t_cd, ref_logp = timed(lambda: orc.gpr_fit(orc.RATQUAD, v, X[:, :nc], y[:nc], 0.1)["logp"], 1)
 t_cg, ref_grad = timed(lambda: orc.fit_gradient(orc.RATQUAD, v, X[:, :nc], y[:nc]), 1)
@@ -46,6 +52,7 @@ print(json.dumps({
     "dens_ms": round(t_dens * 1e3, 2), "dens_tflops": round((n ** 3 / 3) / t_dens * 1e-12, 2),
     "dens_deriv_ms": round(t_grad * 1e3, 2), "dens_deriv_tflops": round((4 * n ** 3 / 3) / t_grad * 1e-12, 2),
     "deriv_rowsum_kernel_ms": round(prof["deriv_rowsum"]["ms"] / prof["deriv_rowsum"]["count"], 3) if "deriv_rowsum" in prof else None,
+    "small_n": {"n": 51, "d": 1, "dens_ms": round(t_small * 1e3, 3), "cpu_oracle_dens_ms": round(t_small_o * 1e3, 3)},
     "cpu_oracle": {"n": nc, "threads": 1, "dens_ms": round(t_cd * 1e3, 1), "dens_deriv_ms": round(t_cg * 1e3, 1)},
     "parity_at_cpu_sample": {"dens_rel": abs(chk_l - ref_logp) / abs(ref_logp),
                              "grad_rel": float(np.max(np.abs(chk_g - ref_grad)) / np.max(np.abs(ref_grad)))},
