@@ -78,3 +78,21 @@ covariance_matrix <- function(A, B, covariance_function) {
   sapply(seq_len(nrow(lat)), function(i) integrate(function(z)
     private$.sigmoid(z) * dnorm(z, mean = lat[i, 1], sd = lat[i, 2]), -Inf, Inf)$value)
 }
+
+# fit(): the two closures optim() is given (R/fit.R:117-139), native branch.  `id` is the kernel id of cov_dict[[cov]]$func
+.dens_native <- function(id, X, y, noise) function(v) .Call(gprc_R_log_marginal, id, as.double(v), X, as.double(y), as.double(noise))
+.dens_deriv_native <- function(id, X, y) function(v) .Call(gprc_R_fit_gradient, id, as.double(v), X, as.double(y))
+
+# multivariate_normal (R/GPRclass.R:360-370), native branch: rnorm() stays in R, the factorisation and L %*% Z move
+multivariate_normal <- function(n, mean, covariance, tol = 1e-6) {
+  stopifnot(length(mean) == nrow(covariance))
+  Z <- matrix(rnorm(n * length(mean), 0, 1), nrow = length(mean))
+  if (!gprc_native_available()) return(drop(mean) + .mvn_factor_R(covariance, tol) %*% Z)   # the original lines :362-368
+  .Call(gprc_R_mvn_sample, as.double(mean), covariance, as.double(tol), Z)
+}
+
+# combine_all (R/simulation.R:338-349), native branch
+combine_all <- function(lst) {
+  if (!gprc_native_available()) return(.combine_all_R(lst))                                   # the original body
+  .Call(gprc_R_combine_all, as.double(unlist(lst)), as.double(lengths(lst)))
+}

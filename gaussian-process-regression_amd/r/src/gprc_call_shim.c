@@ -154,6 +154,54 @@ SEXP gprc_R_gpc_predict_latent(SEXP handle, SEXP X_star) {
   return res;
 }
 
+/* dens(v) of fit()  --  R/fit.R:117-124.  Returns the log marginal likelihood; not positive definite -> R error,
+ * which optim_until_error's tryCatch turns into the -10000 sentinel exactly as it does for chol()'s error. */
+SEXP gprc_R_log_marginal(SEXP kernel, SEXP params, SEXP X, SEXP y, SEXP noise) {
+  const int64_t d = Rf_nrows(X), n = Rf_ncols(X);
+  double logp = 0.0;
+  int rc = gprc_gpr_log_marginal(ctx(), Rf_asInteger(kernel), REAL(params), LENGTH(params), REAL(X), d, n, REAL(y), Rf_asReal(noise), &logp);
+  if (rc > 0) Rf_error("the leading minor of order %d is not positive definite", rc);
+  if (rc != 0) Rf_error("gprc: %s", gprc_last_error());
+  return Rf_ScalarReal(logp);
+}
+
+/* dens_deriv(v) of fit()  --  R/fit.R:126-139 (as written; see gprc_native.h) */
+SEXP gprc_R_fit_gradient(SEXP kernel, SEXP params, SEXP X, SEXP y) {
+  const int64_t d = Rf_nrows(X), n = Rf_ncols(X);
+  SEXP g = PROTECT(Rf_allocVector(REALSXP, LENGTH(params)));
+  int rc = gprc_fit_gradient(ctx(), Rf_asInteger(kernel), REAL(params), LENGTH(params), REAL(X), d, n, REAL(y), REAL(g));
+  UNPROTECT(1);
+  if (rc > 0) Rf_error("system is computationally singular (leading minor of order %d)", rc);   /* solve(K)'s condition */
+  if (rc != 0) Rf_error("gprc: %s", gprc_last_error());
+  return g;
+}
+
+/* multivariate_normal(n, mean, covariance, tol)  --  R/GPRclass.R:360-370.  Z = matrix(rnorm(n * length(mean)), nrow =
+ * length(mean)) is drawn by the R caller, so set.seed() keeps governing the draws. */
+SEXP gprc_R_mvn_sample(SEXP mean, SEXP covariance, SEXP tol, SEXP Z) {
+  const int64_t m = Rf_nrows(covariance), nd = Rf_ncols(Z);
+  SEXP out = PROTECT(Rf_allocMatrix(REALSXP, (int)m, (int)nd));
+  int method = 0;
+  int rc = gprc_mvn_sample(ctx(), REAL(covariance), m, m, REAL(mean), Rf_asReal(tol), REAL(Z), nd, REAL(out), &method);
+  UNPROTECT(1);
+  if (rc == GPRC_ERR_NOT_PD) Rf_error("all(eigval > -tol * abs(eigval[1])) is not TRUE");
+  if (rc != 0) Rf_error("gprc: %s", gprc_last_error());
+  return out;
+}
+
+/* combine_all(lst)  --  R/simulation.R:338-349; `values` = unlist(lst), `lengths` = lengths(lst) as doubles */
+SEXP gprc_R_combine_all(SEXP values, SEXP lengths) {
+  const int d = LENGTH(lengths);
+  int64_t len[64], total = 1;
+  if (d < 1 || d > 64) Rf_error("gprc: combine_all supports 1..64 axes");
+  for (int k = 0; k < d; ++k) { len[k] = (int64_t)REAL(lengths)[k]; total *= len[k]; }
+  SEXP out = PROTECT(Rf_allocMatrix(REALSXP, d, (int)total));
+  int rc = gprc_combine_all(ctx(), REAL(values), len, d, REAL(out));
+  UNPROTECT(1);
+  if (rc != 0) Rf_error("gprc: %s", gprc_last_error());
+  return out;
+}
+
 SEXP gprc_R_device_count(void) {
   int c = 0;
   gprc_device_count(&c);
@@ -168,6 +216,10 @@ static const R_CallMethodDef call_methods[] = {
     {"gprc_R_gpc_fit", (DL_FUNC)&gprc_R_gpc_fit, 5},
     {"gprc_R_gpc_predict_latent", (DL_FUNC)&gprc_R_gpc_predict_latent, 2},
     {"gprc_R_gpc_predict_class", (DL_FUNC)&gprc_R_gpc_predict_class, 2},
+    {"gprc_R_log_marginal", (DL_FUNC)&gprc_R_log_marginal, 5},
+    {"gprc_R_fit_gradient", (DL_FUNC)&gprc_R_fit_gradient, 4},
+    {"gprc_R_mvn_sample", (DL_FUNC)&gprc_R_mvn_sample, 4},
+    {"gprc_R_combine_all", (DL_FUNC)&gprc_R_combine_all, 2},
     {"gprc_R_device_count", (DL_FUNC)&gprc_R_device_count, 0},
     {NULL, NULL, 0}};
 
