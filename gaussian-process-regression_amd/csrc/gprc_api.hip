@@ -229,7 +229,8 @@ struct DevMem {  // scoped device allocation
 };
 
 int make_spec(int kernel, const double* params, int n_params, int64_t d, KernelSpec* ks) {
-  if (n_params < 0 || n_params > MAX_PARAMS || (n_params > 0 && !params)) { set_error("bad kernel parameter vector"); return GPRC_ERR_ARG; }
+  if (n_params > MAX_PARAMS) { set_error("at most 256 kernel parameters (a per-coordinate sigma of the linear kernel needs d <= 256; a scalar sigma has no limit)"); return GPRC_ERR_ARG; }
+  if (n_params < 0 || (n_params > 0 && !params)) { set_error("bad kernel parameter vector"); return GPRC_ERR_ARG; }
   bool ok = false;
   switch (kernel) {
     case GPRC_CONSTANT: ok = n_params == 1; break;

@@ -16,7 +16,7 @@ namespace gprc {
 constexpr int NB = GPRC_NB;  // outer panel width: K-depth of the trailing update (NB/8 flop per byte of C traffic)
 constexpr int NBI = 128;  // inner block: one LDS-resident diagonal factorisation, one GEMM tile edge
 constexpr int TPP = NB / NBI;  // 128-wide tile columns per panel
-constexpr int MAX_PARAMS = 64;
+constexpr int MAX_PARAMS = 256;  // kernel parameters travel as kernel arguments; only linear's per-coordinate sigma needs more than 2
 constexpr int MAX_DEVICES = 64;  // per-device one-time setup flags
 static_assert(NB % NBI == 0 && NB >= NBI, "panel width must be a multiple of the 128 block");
 

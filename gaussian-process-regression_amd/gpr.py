@@ -162,11 +162,12 @@ class GPR:
             pass
 
 
-def _need(value, name, kernel):
-    if value is None:
-        raise NotImplementedError(f"GPR.{kernel}: `{name}` defaults to fit(X, y, noise, \"{kernel}\")$par in the reference; "
-                                  "fit() is not part of the MI355X hot path yet -- pass it explicitly")
-    return value
+def _fitted(X, y, noise, kernel, ctx=None):
+    """fit(X, y, noise, "<kernel>")$par -- the default of every kernel-specific constructor's parameters
+    (R/GPRclass.R:286,297,308-309,320,332-333,344-345).  The reference evaluates it once per missing argument; the
+    result is the same, so one call serves both."""
+    from .fit import fit as _fit
+    return _fit(X, y, noise, [kernel], ctx=ctx)["par"]
 
 
 def _len(x):
@@ -177,7 +178,8 @@ class GPR_constant(GPR):
     """GPR.constant$new(X, y, noise, c)  --  R/GPRclass.R:284-292."""
 
     def __init__(self, X, y, noise, c=None, **kw):
-        c = _need(c, "c", "constant")
+        if c is None:
+            c = _fitted(X, y, noise, "constant", kw.get("ctx"))[0]
         if not (np.isreal(c) and np.all(np.asarray(c) > 0)):
             raise ValueError("is.numeric(c), c > 0 are not all TRUE")
         super().__init__(X, y, noise, cov_func(constant, c=c), **kw)
@@ -187,7 +189,8 @@ class GPR_linear(GPR):
     """GPR.linear$new(X, y, noise, sigma)  --  R/GPRclass.R:295-303."""
 
     def __init__(self, X, y, noise, sigma=None, **kw):
-        sigma = _need(sigma, "sigma", "linear")
+        if sigma is None:
+            sigma = _fitted(X, y, noise, "linear", kw.get("ctx"))[0]          # a scalar: passes :298 only for one-dimensional X
         if _len(sigma) != as_points(X).shape[0]:
             raise ValueError("length(sigma) == nrow(X) is not TRUE")
         super().__init__(X, y, noise, cov_func(linear, sigma=sigma), **kw)
@@ -197,7 +200,9 @@ class GPR_polynomial(GPR):
     """GPR.polynomial$new(X, y, noise, sigma, p)  --  R/GPRclass.R:306-315."""
 
     def __init__(self, X, y, noise, sigma=None, p=None, **kw):
-        sigma, p = _need(sigma, "sigma", "polynomial"), _need(p, "p", "polynomial")
+        if sigma is None or p is None:
+            par = _fitted(X, y, noise, "polynomial", kw.get("ctx"))
+            sigma, p = (par[0] if sigma is None else sigma), (par[1] if p is None else p)
         if _len(sigma) != 1 or _len(p) != 1:
             raise ValueError("length(sigma) == 1, length(p) == 1 are not all TRUE")
         super().__init__(X, y, noise, cov_func(polynomial, sigma=sigma, p=p), **kw)
@@ -207,7 +212,8 @@ class GPR_sqrexp(GPR):
     """GPR.sqrexp$new(X, y, noise, l)  --  R/GPRclass.R:318-327."""
 
     def __init__(self, X, y, noise, l=None, **kw):
-        l = _need(l, "l", "sqrexp")
+        if l is None:
+            l = _fitted(X, y, noise, "sqrexp", kw.get("ctx"))[0]
         if _len(l) != 1:
             raise ValueError("length(l) == 1 is not TRUE")
         super().__init__(X, y, noise, cov_func(sqrexp, l=l), **kw)
@@ -217,7 +223,9 @@ class GPR_gammaexp(GPR):
     """GPR.gammaexp$new(X, y, noise, gamma, l)  --  R/GPRclass.R:330-339."""
 
     def __init__(self, X, y, noise, gamma=None, l=None, **kw):
-        gamma, l = _need(gamma, "gamma", "gammaexp"), _need(l, "l", "gammaexp")
+        if gamma is None or l is None:   # as written in :332-333: gamma <- $par[[1]], l <- $par[[2]], although fit's par is (l, gamma)
+            par = _fitted(X, y, noise, "gammaexp", kw.get("ctx"))
+            gamma, l = (par[0] if gamma is None else gamma), (par[1] if l is None else l)
         if _len(gamma) != 1 or _len(l) != 1:
             raise ValueError("length(gamma) == 1, length(l) == 1 are not all TRUE")
         super().__init__(X, y, noise, cov_func(gammaexp, l=l, gamma=gamma), **kw)
@@ -227,7 +235,9 @@ class GPR_rationalquadratic(GPR):
     """GPR.rationalquadratic$new(X, y, noise, alpha, l)  --  R/GPRclass.R:342-351."""
 
     def __init__(self, X, y, noise, alpha=None, l=None, **kw):
-        alpha, l = _need(alpha, "alpha", "rationalquadratic"), _need(l, "l", "rationalquadratic")
+        if alpha is None or l is None:   # as written in :344-345: alpha <- $par[[1]], l <- $par[[2]], although fit's par is (l, alpha)
+            par = _fitted(X, y, noise, "rationalquadratic", kw.get("ctx"))
+            alpha, l = (par[0] if alpha is None else alpha), (par[1] if l is None else l)
         if _len(alpha) != 1 or _len(l) != 1:
             raise ValueError("length(alpha) == 1, length(l) == 1 are not all TRUE")
         super().__init__(X, y, noise, cov_func(rationalquadratic, l=l, alpha=alpha), **kw)

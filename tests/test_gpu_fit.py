@@ -136,3 +136,23 @@ def test_fit_bfgs_kernels_follow_the_reference_driver():
     full = fit(Xd, yd, 0.1)
     assert full["cov"] in ("sqrexp", "gammaexp", "constant", "linear", "polynomial", "rationalquadratic") and len(full["score"]) == 6
     assert GPR(Xd, yd, 0.1, full["func"]).predict(Xd[:, :5]).shape == (5, 2)
+
+
+def test_kernel_specific_constructors_default_to_fit():
+    """GPR.<kernel>$new(X, y, noise) with the parameters left out: each defaults to fit(X, y, noise, "<kernel>")$par
+    (R/GPRclass.R:286-345), including the as-written assignment gamma <- par[[1]], l <- par[[2]] for gammaexp."""
+    y = 5 * np.exp(-x ** 2)
+    g = GPR.sqrexp.new(X, y, 0.05)
+    assert g.k.gprc_kernel[1][0] == fit(X, y, 0.05, ["sqrexp"])["par"][0]
+    gp = GPR.polynomial.new(X, y, 0.05)
+    assert tuple(gp.k.gprc_kernel[1]) == fit(X, y, 0.05, ["polynomial"])["par"]
+    gc = GPR.constant.new(X, y, 0.05)
+    assert gc.k.gprc_kernel[1][0] == fit(X, y, 0.05, ["constant"])["par"][0]
+    gl = GPR.linear.new(X, y, 0.05)                                    # one-dimensional X: the scalar sigma passes :298
+    assert gl.k.gprc_kernel[1][0] == fit(X, y, 0.05, ["linear"])["par"][0]
+    gg = GPR.gammaexp.new(X, y, 0.05)                                  # fit returns the start values (1, 1) for gammaexp
+    assert tuple(gg.k.gprc_kernel[1]) == (1.0, 1.0)
+    gs = GPR.sqrexp.new(X, y, 0.05, l=0.5)                             # explicit parameters never trigger fit()
+    assert gs.k.gprc_kernel[1][0] == 0.5
+    with pytest.raises(ValueError, match="length\\(sigma\\) == nrow\\(X\\)"):
+        GPR.linear.new(np.vstack([x, x ** 2]), y, 0.05)                # d = 2: the fitted scalar sigma fails :298, as in R

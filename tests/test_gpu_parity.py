@@ -11,7 +11,7 @@ import pytest
 
 from conftest import TOL, nerr, oracle_params
 import gprc_amd
-from gprc_amd import (GPR, GPC, NotPositiveDefinite, cov_func, covariance_matrix, constant, linear, polynomial, sqrexp,
+from gprc_amd import (GPR, GPC, GprcError, NotPositiveDefinite, cov_func, covariance_matrix, constant, linear, polynomial, sqrexp,
                       gammaexp, rationalquadratic)
 from gprc_amd import _native as nat
 from oracle import oracle as orc
@@ -346,3 +346,35 @@ def test_predict_class_native_matches_reference_method(golden):
         native = gc.predict_class(Xs)
         quadpack = gc.predict_class(Xs, integrator="quadpack")
         assert nerr(native, quadpack) <= 1e-7 and nerr(native, golden.get(c, "prob")) <= 1e-7, c["name"]
+
+
+def test_wide_inputs_and_non_finite_values():
+    """d far beyond the LDS staging width (16 coordinates per pass), linear's per-coordinate sigma at d = 100 and its
+    documented limit, and NaN / Inf inputs: the reference's chol() fails on them through all ten jitter attempts."""
+    rng = np.random.default_rng(17)
+    d, n, ns = 100, 150, 40
+    X = rng.uniform(-1, 1, (d, n)) / np.sqrt(d)
+    y = rng.normal(size=n)
+    Xs = rng.uniform(-1, 1, (d, ns)) / np.sqrt(d)
+    sig = rng.uniform(0.5, 1.5, d)
+    for name, kid, kw, par in [("sqrexp", orc.SQREXP, dict(l=0.7), [0.7]), ("rationalquadratic", orc.RATQUAD, dict(l=0.7, alpha=1.5), [0.7, 1.5]),
+                               ("gammaexp", orc.GAMMAEXP, dict(l=0.7, gamma=1.3), [0.7, 1.3]), ("polynomial", orc.POLYNOMIAL, dict(sigma=0.5, p=3.0), [0.5, 3.0]),
+                               ("linear", orc.LINEAR, dict(sigma=sig), list(sig))]:
+        g = GPR(X, y, 0.1, cov_func(GENERIC[name], **kw))
+        ref = orc.gpr_fit(kid, par, X, y, 0.1)
+        mean, var = orc.gpr_predict(kid, par, X, ref["L"], ref["alpha"], Xs)
+        pr = g.predict(Xs)
+        assert nerr(g.alpha, ref["alpha"]) <= TOL and nerr(pr[:, 0], mean) <= TOL and nerr(pr[:, 1], var) <= TOL, name
+    with pytest.raises(GprcError, match="256"):
+        GPR(np.zeros((300, 4)) + np.arange(4), np.arange(4.0), 0.1, cov_func(linear, sigma=np.ones(300)))
+    Xbad = rng.uniform(-1, 1, (2, 30))
+    for bad in (np.nan, np.inf):
+        Xb = Xbad.copy()
+        Xb[1, 7] = bad
+        with pytest.raises(ArithmeticError, match="non positive definite"):
+            GPR(Xb, rng.normal(size=30), 0.1, cov_func(sqrexp, l=1.0))
+    yb = rng.normal(size=30)
+    yb[3] = np.nan                                                       # NaN target: the factor is fine, alpha and the mean are NaN (as in R)
+    g = GPR(Xbad, yb, 0.1, cov_func(sqrexp, l=1.0))
+    assert np.isnan(g.alpha).all() or np.isnan(g.alpha).any()
+    assert np.isnan(g.predict(Xbad[:, :3])[:, 0]).all() and np.isfinite(g.predict(Xbad[:, :3])[:, 1]).all()
