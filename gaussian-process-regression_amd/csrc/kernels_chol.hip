@@ -114,8 +114,9 @@ __global__ __launch_bounds__(TY * 128) void potf2_inv_kernel(double* A, int64_t 
 // Blocked diagonal-block kernel (default): the same factor + inverse, 16 columns at a time.
 // The 128 x 128 block lives in LDS (leading dimension 144: MFMA operand reads conflict-free).  Per 16-column step:
 //   A  wave 0 factors the 16 x 16 diagonal sub-block and inverts it with the register-resident scalar sweep above
-//      (16 sequential pivots; sqrt / reciprocal from a Newton-refined v_rsq_f64 -- ~100 dependent cycles instead of
-//      the ~600 of the library sqrt + division);
+//      (16 sequential pivots; operands exchanged between lanes by ds_bpermute, no LDS memory round trip; sqrt /
+//      reciprocal from a Newton-refined v_rsq_f64 -- ~60 dependent cycles instead of the ~600 of the library
+//      sqrt + division);
 //   B  panel rows below: X_I = A_I * Wd^T, and row s of the inverse: X_sJ = Wd * Y_sJ   (4 MFMAs per 16x16 block);
 //   C  Cholesky trailing blocks C_IJ -= X_I X_J^T and inverse blocks Y_IJ -= L_Is X_sJ  (4 MFMAs per block),
 // one barrier after each phase.  L is kept in the lower triangle, the (unscaled-free) inverse transposed in the
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(TY * 128) void potf2_inv_kernel(double* A, int64_t 
 // whole-workgroup steps to 128 single-wave steps on 16-row data.
 // ------------------------------------------------------------------------------------------------
 constexpr int BLD = 144;
-constexpr int PB_SMEM_DOUBLES = PB * BLD + 256 + PB + 2 * 20;  // S, Wd, Wdiag, 2 publish lines
+constexpr int PB_SMEM_DOUBLES = PB * BLD + 256 + PB;  // S, Wd, Wdiag
 
 // sqrt(d) and 1/sqrt(d) from v_rsq_f64 + two Newton steps (+ one correction of the root)
 __device__ __forceinline__ void sqrt_rsqrt(double d, double& root, double& rinv) {
@@ -139,14 +140,14 @@ __device__ __forceinline__ void sqrt_rsqrt(double d, double& root, double& rinv)
   rinv = r;
 }
 
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
-  __builtin_amdgcn_wave_barrier();
-}
-
 // Phase A: one wave (64 lanes) factors the 16x16 block at D (LDS, ld BLD) in place (lower), writes its inverse
 // dense to Wd[16][16] (column-major), transposed-strict-lower into D's upper triangle and the diagonal to wdiag.
-__device__ __forceinline__ void diag16(double* D, double* Wd, double* wdiag, double* lines, int* info, int col) {
+// Lane (i = lane & 15, ty = lane >> 4) holds row i, columns ty + 4k (k = 0..3), in registers.  Column j = 4 kb + jj:
+// every lane needs the pivot, its own row's column-j entry and "line[c]" for its four columns c (c < j: row j of the
+// running inverse; c >= j: column j at row c).  All of them come straight out of other lanes' registers with
+// ds_bpermute (__shfl) -- six 64-bit shuffles issued back to back, one LDS-crossbar latency per column.  (Publishing
+// the line through LDS memory instead cost three dependent LDS round trips per column: 800 cycles against ~300.)
+__device__ __forceinline__ void diag16(double* D, double* Wd, double* wdiag, int* info, int col) {
   const int l = threadIdx.x & 63, i = l & 15, ty = l >> 4;
   double reg[4];
   double my_rinv = 1.0;
@@ -160,26 +161,22 @@ __device__ __forceinline__ void diag16(double* D, double* Wd, double* wdiag, dou
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int j = kb * 4 + jj;
-      double* line = lines + (j & 1) * 20;
-      if (ty == jj && i >= j) line[i] = reg[kb];
-      if (i == j) {
+      const double d = __shfl(reg[kb], jj * 16 + j, 64);    // pivot: row j, held by ty == jj
+      const double wij = __shfl(reg[kb], jj * 16 + i, 64);  // column j at this lane's row
+      double lv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int c = ty + 4 * k;
-          if (c < j) line[c] = reg[k];
-        }
+      for (int k = 0; k < 4; ++k) {
+        const int c = ty + 4 * k;
+        if (k < kb) lv[k] = __shfl(reg[k], ty * 16 + j, 64);          // c < j: inverse row j
+        else if (k > kb) lv[k] = __shfl(reg[kb], jj * 16 + c, 64);    // c > j: column j at row c
+        else lv[k] = __shfl(reg[kb], (ty < jj) ? ty * 16 + j : jj * 16 + c, 64);
       }
-      wave_lds_sync();
-      const double d = line[j];
       if (!(d > 0.0) && l == 0) atomicCAS(info, 0, col + j + 1);  // LAPACK info: first non-PD leading minor
       double ljj, rinv;
       sqrt_rsqrt(d, ljj, rinv);
       const bool below = i > j;
-      const double lij = below ? line[i] * rinv : 0.0;
+      const double lij = below ? wij * rinv : 0.0;
       const double mult = -lij * rinv;
-      double lv[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) lv[k] = line[ty + 4 * k];
 #pragma unroll
       for (int k = 0; k < 4; ++k) reg[k] = fma(mult, lv[k], reg[k]);
       if (ty == jj) {
@@ -215,7 +212,6 @@ __global__ __launch_bounds__(1024) void potf2_inv_blocked_kernel(double* A, int6
   double* S = sm;                      // PB x BLD
   double* Wd = sm + PB * BLD;          // 16 x 16
   double* Wdiag = Wd + 256;            // PB
-  double* lines = Wdiag + PB;          // 2 x 20
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int q = lane >> 4, r = lane & 15;
@@ -226,7 +222,7 @@ __global__ __launch_bounds__(1024) void potf2_inv_blocked_kernel(double* A, int6
   __syncthreads();
   for (int s = 0; s < 8; ++s) {
     const int c0 = 16 * s, m = 7 - s;
-    if (wave == 0) diag16(S + c0 + c0 * BLD, Wd, Wdiag + c0, lines, info, col0 + c0);
+    if (wave == 0) diag16(S + c0 + c0 * BLD, Wd, Wdiag + c0, info, col0 + c0);
     __syncthreads();
     // ---- phase B: panel below (waves 0..m-1), inverse row s (waves 8..8+s-1)
     if (wave < m) {
