@@ -226,10 +226,10 @@ def main():
             kernels[name] = {"launches": r["count"], "ms_total": round(r["ms"], 3), "avg_ms": round(r["ms"] / r["count"], 4),
                              "tflops": round(r["flops"] / r["ms"] * 1e-9, 3) if r["ms"] > 0 else None,
                              "gbs": round(r["bytes"] / r["ms"] * 1e-6, 1) if r["ms"] > 0 else None}
-        dom_name = max(("solve_update_k512", "trailing_update"), key=lambda k: prof[k]["ms"])
+        dom_name = max(("solve_left", "solve_update_k512", "trailing_update"), key=lambda k: prof[k]["ms"])
         dom = prof[dom_name]
         achieved = dom["flops"] / dom["ms"] * 1e-9 if dom["ms"] > 0 else 0.0
-        symbol = {"solve_update_k512": "gemm_nt_kernel<5>", "trailing_update": "trailing_kernel"}[dom_name]
+        symbol = {"solve_left": "solve_left_kernel", "solve_update_k512": "gemm_nt_kernel<5>", "trailing_update": "trailing_kernel"}[dom_name]
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
         # comes from the separate rocprofv3 --pmc passes of the same command stored under profiles/ (see the JSON's
         # `source`), per launch and corrected as MI355X_MICROARCH.md prescribes; null when no matching profile.

@@ -285,13 +285,21 @@ int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* 
   return 0;
 }
 
-// vt (m_pad x n_pad) := vt * L^-T
+// vt (m_pad x n_pad) := vt * L^-T.  Two schedules with bit-identical results (same products, same order):
+//   right-looking: after panel p is solved, subtract its contribution from every column to the right (K = NB per pass);
+//   left-looking:  before panel p is solved, subtract the contributions of ALL earlier panels in one pass (K = p NB),
+//                  the C tile staying in the accumulators -- one C load/store and one tile prologue instead of p.
+// Left-looking has only (m_pad / 128) * 4 tiles per pass, so it is used when that fills the GPU several times over
+// (GPRC_SOLVE=left|right overrides).
 int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt, int64_t ldv, int64_t m_pad) {
   hipStream_t s = ctx->stream;
   const int64_t P = n_pad / NB;
+  const char* mode = std::getenv("GPRC_SOLVE");
+  const bool left = mode ? (std::strcmp(mode, "left") == 0) : ((m_pad / 128) * (NB / NBI) >= 1024);
   for (int64_t p = 0; p < P; ++p) {
     const int64_t ld = panel_ld(n_pad, p);
     const double* pan = packed + panel_offset(n_pad, p);
+    if (left) GPRC_TRY(launch_solve_left(s, vt, ldv, m_pad, packed, n_pad, p));
     for (int j = 0; j < NB / NBI; ++j) {
       const int64_t cj = p * NB + (int64_t)j * NBI;  // global column
       const double* wblk = winv + (p * (NB / NBI) + j) * NBI * NBI;
@@ -302,7 +310,7 @@ int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t 
                                 m_pad, rest, NBI, 0, PK_GEMM_INNER));
     }
     const int64_t right = n_pad - (p + 1) * NB;
-    if (right > 0)
+    if (!left && right > 0)
       GPRC_TRY(launch_gemm_nt(s, vt + (p + 1) * NB * ldv, ldv, vt + p * NB * ldv, ldv, pan + NB, ld, m_pad, right, NB, 0, PK_SOLVE_UPDATE));
   }
   return 0;

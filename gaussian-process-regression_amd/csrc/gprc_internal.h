@@ -42,7 +42,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 // ---- in-library event profiler (bench.py's live roofline numbers) ---------------------------------
 enum ProfKind { PK_FILL = 0, PK_POTF2 = 1, PK_TRSM_PANEL = 2, PK_GEMM_INNER = 3, PK_TRAILING = 4, PK_SOLVE_UPDATE = 5,
-                PK_TRSV = 6, PK_ROWREDUCE = 7, PK_COV_SYRK = 8, PK_DERIV = 9, PK_JACOBI = 10, PK_COUNT = 11 };
+                PK_TRSV = 6, PK_ROWREDUCE = 7, PK_COV_SYRK = 8, PK_DERIV = 9, PK_JACOBI = 10, PK_SOLVE_LEFT = 11, PK_COUNT = 12 };
 bool prof_enabled();
 void prof_begin(hipStream_t s, int kind);
 void prof_end(hipStream_t s, int kind, double flops, double bytes);
@@ -85,6 +85,8 @@ int launch_trsm_panel(hipStream_t s, double* X, int64_t ldx, int64_t M, const do
 int launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
                    int64_t M, int64_t N, int64_t K, int lower, int kind);
 // trailing update of packed panels q_begin, q_begin+q_stride, ... < q_end with factored panel p
+// left-looking predict-solve step: vt[:, j NB:(j+1) NB] -= vt[:, 0:j NB] * L[j NB:(j+1) NB, 0:j NB]^T   (L packed)
+int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t j);
 int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t p, int64_t q_begin, int64_t q_end,
                            int64_t q_stride);
 

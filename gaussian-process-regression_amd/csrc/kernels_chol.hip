@@ -329,9 +329,23 @@ __device__ __forceinline__ void dma_ktile(const double* Ag, int64_t lda, const d
   }
 }
 
-template <bool SET>
+// SEG: the B strip is rows [brow, brow + 128) of the PACKED factor across its first K columns (B = packed base,
+// ldb = n_pad): every NB columns the strip moves to the next panel, with that panel's own leading dimension.
+template <bool SEG>
+__device__ __forceinline__ const double* b_ktile(const double* B, int64_t ldb, int64_t brow, int kt, int lane, int wave, int64_t& ld) {
+  if constexpr (SEG) {
+    const int pp = kt / (NB / 16);                    // panel that holds k-tile kt
+    ld = panel_ld(ldb, pp);
+    return B + panel_offset(ldb, pp) + (brow - (int64_t)pp * NB) + (int64_t)((kt % (NB / 16)) * 16 + wave) * ld + 2 * lane;
+  } else {
+    ld = ldb;
+    return B + 2 * lane + (int64_t)(kt * 16 + wave) * ldb;
+  }
+}
+
+template <bool SET, bool SEG = false>
 __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
-                                              int64_t ldb, int K, double* smem) {
+                                              int64_t ldb, int K, double* smem, int64_t brow = 0) {
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -352,7 +366,8 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
       for (int m = 0; m < 4; ++m) acc[m][n][r] = SET ? 0.0 : Cw[m * 16 + (int64_t)(n * 16 + 4 * r) * ldc];
 
   const double* Ag = A + 2 * lane + (int64_t)wave * lda;  // this lane's 16 bytes of k-slice `wave`
-  const double* Bg = B + 2 * lane + (int64_t)wave * ldb;
+  int64_t ldbk;
+  const double* Bg = b_ktile<SEG>(B, ldb, brow, 0, lane, wave, ldbk);
   const int srow = wave * G_LDT;                          // LDS row of that slice (wave-uniform)
   const int foff = fr + fk * G_LDT;                       // this lane's MFMA operand element
 
@@ -366,14 +381,17 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
   // so a DMA has 64 MFMAs (4096 cycles) to land, as before.
   constexpr int LGKM0 = 0xC07F;  // s_waitcnt lgkmcnt(0), vmcnt/expcnt untouched
   const int KT = K / G_KB;
-  dma_ktile(Ag, lda, Bg, ldb, As + srow, Bs + srow);
+  dma_ktile(Ag, lda, Bg, ldbk, As + srow, Bs + srow);
   // vmcnt(0) through the BUILTIN, not inline asm, so that the compiler's waitcnt pass knows the C-tile loads
   // above have completed and does not re-wait vmcnt(0) (draining fresh DMAs) inside the loop.  0x0F70 = vmcnt(0).
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
-  if (KT > 1) dma_ktile(Ag + (int64_t)G_KB * lda, lda, Bg + (int64_t)G_KB * ldb, ldb, As + G_BUF + srow, Bs + G_BUF + srow);
+  if (KT > 1) {
+    Bg = b_ktile<SEG>(B, ldb, brow, 1, lane, wave, ldbk);
+    dma_ktile(Ag + (int64_t)G_KB * lda, lda, Bg, ldbk, As + G_BUF + srow, Bs + G_BUF + srow);
+  }
   Ag += (int64_t)2 * G_KB * lda;  // next tile to request: kt + 2
-  Bg += (int64_t)2 * G_KB * ldb;
+  if constexpr (!SEG) Bg = B + 2 * lane + (int64_t)(2 * G_KB + wave) * ldb;
   double a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
   read_ops(As + wr * 64 + foff, Bs + wc * 64 + foff, 0, a0, b0);
   read_ops(As + wr * 64 + foff, Bs + wc * 64 + foff, 1, a1, b1);
@@ -398,9 +416,10 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 has landed (this wave's share)
       __syncthreads();                                   // ... everyone's share; and buffer `cur` is drained
       if (kt + 2 < KT) {
-        dma_ktile(Ag, lda, Bg, ldb, As + cur + srow, Bs + cur + srow);
+        if constexpr (SEG) Bg = b_ktile<true>(B, ldb, brow, kt + 2, lane, wave, ldbk);
+        dma_ktile(Ag, lda, Bg, ldbk, As + cur + srow, Bs + cur + srow);
         Ag += (int64_t)G_KB * lda;
-        Bg += (int64_t)G_KB * ldb;
+        if constexpr (!SEG) Bg += (int64_t)G_KB * ldb;
       }
       read_ops(An, Bn, 0, a0, b0);
     }
@@ -494,6 +513,27 @@ __global__ __launch_bounds__(256, 2) void trailing_kernel(double* packed, int64_
   }
 }
 
+
+// Left-looking step of the predict solve: the NB columns of panel j of vt receive, in ONE pass with the C tile held
+// in the accumulators, everything the right-looking form would have subtracted panel by panel:
+//   vt[:, j NB : (j+1) NB] -= vt[:, 0 : j NB] * L[j NB : (j+1) NB, 0 : j NB]^T          (K = j NB).
+// Same products in the same order (k ascending from the loaded C value), so the result is bit-identical; what
+// changes is that a C tile is loaded and stored once instead of j times -- the per-tile prologue (C preload + first
+// DMA, ~7 % of a K = 512 tile during which the tile's waves issue no MFMA) is paid once per j NB of K.
+__global__ __launch_bounds__(256, 2) void solve_left_kernel(double* vt, int64_t ldv, const double* packed, int64_t n_pad, int j,
+                                                            int tiles_m, int group) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const unsigned ntiles = (unsigned)tiles_m * TPP;
+  const unsigned id = xcd_remap(blockIdx.x, ntiles);
+  const int width = group * TPP;
+  const int g = id / width, first_m = g * group;
+  const int gsize = (tiles_m - first_m < group) ? (tiles_m - first_m) : group;
+  const int tr = first_m + (int)(id % width) % gsize;
+  const int tc = (int)(id % width) / gsize;
+  const int64_t col = (int64_t)j * NB + (int64_t)tc * 128;
+  gemm_tile_128<false, true>(vt + (int64_t)tr * 128 + col * ldv, ldv, vt + (int64_t)tr * 128, ldv, packed, n_pad, j * NB, smem, col);
+}
+
 }  // namespace
 
 int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* info_dev, int col0) {
@@ -528,7 +568,20 @@ static int ensure_gemm_attrs() {
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<PK_COV_SYRK>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_left_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   if (dev >= 0 && dev < MAX_DEVICES) done[dev] = true;
+  return 0;
+}
+
+int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t j) {
+  if (j <= 0 || m_pad <= 0) return 0;
+  if (m_pad % 128) { set_error("solve_left: m_pad must be a multiple of 128"); return GPRC_ERR_ARG; }
+  GPRC_TRY(ensure_gemm_attrs());
+  const int64_t K = j * NB, tiles = (m_pad / 128) * TPP;
+  ProfScope ps(s, PK_SOLVE_LEFT, 2.0 * (double)m_pad * NB * (double)K, 8.0 * (2.0 * m_pad * NB + (double)m_pad * K + (double)NB * K));
+  hipLaunchKernelGGL(solve_left_kernel, dim3((unsigned)tiles), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, vt, ldv, packed, n_pad,
+                     (int)j, (int)(m_pad / 128), 8);
+  GPRC_LAUNCH_CHECK();
   return 0;
 }
 
