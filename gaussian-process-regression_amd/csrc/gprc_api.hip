@@ -285,33 +285,40 @@ int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* 
   return 0;
 }
 
-// vt (m_pad x n_pad) := vt * L^-T.  Two schedules with bit-identical results (same products, same order):
+// vt (m_pad x n_pad) := vt * L^-T.  Schedules with bit-identical results (same products, same order):
 //   right-looking: after panel p is solved, subtract its contribution from every column to the right (K = NB per pass);
-//   left-looking:  before panel p is solved, subtract the contributions of ALL earlier panels in one pass (K = p NB),
-//                  the C tile staying in the accumulators -- one C load/store and one tile prologue instead of p.
-// Left-looking has only (m_pad / 128) * 4 tiles per pass, so it is used when that fills the GPU several times over
-// (GPRC_SOLVE=left|right overrides).
+//   left-looking:  before a GROUP of G panels is solved, subtract the contributions of ALL earlier panels from the
+//                  group's columns in one pass (K = p NB), the C tile staying in the accumulators -- one C load/store
+//                  and one tile prologue instead of p; inside the group the panels update each other right-looking.
+// G is the smallest group that gives a pass (m_pad / 128) * 4 G >= 1024 tiles (two workgroups on each of 256 CUs, twice
+// over); G >= P degenerates to plain right-looking.  GPRC_SOLVE=right forces that, =left forces G = 1, =<n> G = n.
 int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt, int64_t ldv, int64_t m_pad) {
   hipStream_t s = ctx->stream;
   const int64_t P = n_pad / NB;
   const char* mode = std::getenv("GPRC_SOLVE");
-  const bool left = mode ? (std::strcmp(mode, "left") == 0) : ((m_pad / 128) * (NB / NBI) >= 1024);
-  for (int64_t p = 0; p < P; ++p) {
-    const int64_t ld = panel_ld(n_pad, p);
-    const double* pan = packed + panel_offset(n_pad, p);
-    if (left) GPRC_TRY(launch_solve_left(s, vt, ldv, m_pad, packed, n_pad, p));
-    for (int j = 0; j < NB / NBI; ++j) {
-      const int64_t cj = p * NB + (int64_t)j * NBI;  // global column
-      const double* wblk = winv + (p * (NB / NBI) + j) * NBI * NBI;
-      GPRC_TRY(launch_trsm_panel(s, vt + cj * ldv, ldv, m_pad, wblk));
-      const int64_t rest = NB - (j + 1) * NBI;
-      if (rest > 0)
-        GPRC_TRY(launch_gemm_nt(s, vt + (cj + NBI) * ldv, ldv, vt + cj * ldv, ldv, pan + (j + 1) * NBI + (int64_t)j * NBI * ld, ld,
-                                m_pad, rest, NBI, 0, PK_GEMM_INNER));
+  int64_t G = (1024 + (m_pad / 128) * (NB / NBI) - 1) / ((m_pad / 128) * (NB / NBI));
+  if (mode && std::strcmp(mode, "left") == 0) G = 1;
+  else if (mode && std::atoi(mode) > 0) G = std::atoi(mode);  // an explicit group size
+  if ((mode && std::strcmp(mode, "right") == 0) || G > P) G = P;
+  for (int64_t g0 = 0; g0 < P; g0 += G) {
+    const int64_t g1 = std::min(P, g0 + G);  // panels [g0, g1)
+    GPRC_TRY(launch_solve_left(s, vt, ldv, m_pad, packed, n_pad, g0, g1 - g0));
+    for (int64_t p = g0; p < g1; ++p) {
+      const int64_t ld = panel_ld(n_pad, p);
+      const double* pan = packed + panel_offset(n_pad, p);
+      for (int j = 0; j < NB / NBI; ++j) {
+        const int64_t cj = p * NB + (int64_t)j * NBI;  // global column
+        const double* wblk = winv + (p * (NB / NBI) + j) * NBI * NBI;
+        GPRC_TRY(launch_trsm_panel(s, vt + cj * ldv, ldv, m_pad, wblk));
+        const int64_t rest = NB - (j + 1) * NBI;
+        if (rest > 0)
+          GPRC_TRY(launch_gemm_nt(s, vt + (cj + NBI) * ldv, ldv, vt + cj * ldv, ldv, pan + (j + 1) * NBI + (int64_t)j * NBI * ld, ld,
+                                  m_pad, rest, NBI, 0, PK_GEMM_INNER));
+      }
+      const int64_t right = (g1 - (p + 1)) * NB;  // the rest of the group
+      if (right > 0)
+        GPRC_TRY(launch_gemm_nt(s, vt + (p + 1) * NB * ldv, ldv, vt + p * NB * ldv, ldv, pan + NB, ld, m_pad, right, NB, 0, PK_SOLVE_UPDATE));
     }
-    const int64_t right = n_pad - (p + 1) * NB;
-    if (!left && right > 0)
-      GPRC_TRY(launch_gemm_nt(s, vt + (p + 1) * NB * ldv, ldv, vt + p * NB * ldv, ldv, pan + NB, ld, m_pad, right, NB, 0, PK_SOLVE_UPDATE));
   }
   return 0;
 }

@@ -85,8 +85,8 @@ int launch_trsm_panel(hipStream_t s, double* X, int64_t ldx, int64_t M, const do
 int launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
                    int64_t M, int64_t N, int64_t K, int lower, int kind);
 // trailing update of packed panels q_begin, q_begin+q_stride, ... < q_end with factored panel p
-// left-looking predict-solve step: vt[:, j NB:(j+1) NB] -= vt[:, 0:j NB] * L[j NB:(j+1) NB, 0:j NB]^T   (L packed)
-int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t j);
+// left-looking predict-solve step: vt[:, j NB:(j+G) NB] -= vt[:, 0:j NB] * L[j NB:(j+G) NB, 0:j NB]^T   (L packed)
+int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t j, int64_t G);
 int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t p, int64_t q_begin, int64_t q_end,
                            int64_t q_stride);
 

@@ -514,18 +514,18 @@ __global__ __launch_bounds__(256, 2) void trailing_kernel(double* packed, int64_
 }
 
 
-// Left-looking step of the predict solve: the NB columns of panel j of vt receive, in ONE pass with the C tile held
-// in the accumulators, everything the right-looking form would have subtracted panel by panel:
-//   vt[:, j NB : (j+1) NB] -= vt[:, 0 : j NB] * L[j NB : (j+1) NB, 0 : j NB]^T          (K = j NB).
+// Left-looking step of the predict solve: the columns of panels [j, j + G) of vt receive, in ONE pass with the C tile
+// held in the accumulators, everything the right-looking form would have subtracted panel by panel:
+//   vt[:, j NB : (j+G) NB] -= vt[:, 0 : j NB] * L[j NB : (j+G) NB, 0 : j NB]^T          (K = j NB).
 // Same products in the same order (k ascending from the loaded C value), so the result is bit-identical; what
 // changes is that a C tile is loaded and stored once instead of j times -- the per-tile prologue (C preload + first
 // DMA, ~7 % of a K = 512 tile during which the tile's waves issue no MFMA) is paid once per j NB of K.
 __global__ __launch_bounds__(256, 2) void solve_left_kernel(double* vt, int64_t ldv, const double* packed, int64_t n_pad, int j,
-                                                            int tiles_m, int group) {
+                                                            int tiles_m, int tiles_n, int group) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const unsigned ntiles = (unsigned)tiles_m * TPP;
+  const unsigned ntiles = (unsigned)tiles_m * (unsigned)tiles_n;
   const unsigned id = xcd_remap(blockIdx.x, ntiles);
-  const int width = group * TPP;
+  const int width = group * tiles_n;
   const int g = id / width, first_m = g * group;
   const int gsize = (tiles_m - first_m < group) ? (tiles_m - first_m) : group;
   const int tr = first_m + (int)(id % width) % gsize;
@@ -573,14 +573,15 @@ static int ensure_gemm_attrs() {
   return 0;
 }
 
-int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t j) {
-  if (j <= 0 || m_pad <= 0) return 0;
+int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t j, int64_t G) {
+  if (j <= 0 || m_pad <= 0 || G <= 0) return 0;
   if (m_pad % 128) { set_error("solve_left: m_pad must be a multiple of 128"); return GPRC_ERR_ARG; }
+  if ((j + G) * NB > n_pad) { set_error("solve_left: panel group beyond the factor"); return GPRC_ERR_ARG; }
   GPRC_TRY(ensure_gemm_attrs());
-  const int64_t K = j * NB, tiles = (m_pad / 128) * TPP;
-  ProfScope ps(s, PK_SOLVE_LEFT, 2.0 * (double)m_pad * NB * (double)K, 8.0 * (2.0 * m_pad * NB + (double)m_pad * K + (double)NB * K));
+  const int64_t K = j * NB, N = G * NB, tiles = (m_pad / 128) * (N / 128);
+  ProfScope ps(s, PK_SOLVE_LEFT, 2.0 * (double)m_pad * N * (double)K, 8.0 * (2.0 * m_pad * N + (double)m_pad * K + (double)N * K));
   hipLaunchKernelGGL(solve_left_kernel, dim3((unsigned)tiles), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, vt, ldv, packed, n_pad,
-                     (int)j, (int)(m_pad / 128), 8);
+                     (int)j, (int)(m_pad / 128), (int)(N / 128), 8);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

@@ -382,7 +382,8 @@ def test_wide_inputs_and_non_finite_values():
 
 def test_left_and_right_looking_solve_schedules_are_bit_identical(monkeypatch):
     """The predict solve vt := vt L^-T has two schedules (right-looking per panel, left-looking with the C tile held in
-    the accumulators across all earlier panels); same products in the same order, so identical bits."""
+    the accumulators across all earlier panels, for single panels or groups of panels); same products in the same
+    order, so identical bits."""
     rng = np.random.default_rng(23)
     d, n, ns = 3, 1700, 300                       # 4 panels: K = 512, 1024, 1536 in the left-looking passes
     X = rng.uniform(-1, 1, (d, n))
@@ -390,10 +391,11 @@ def test_left_and_right_looking_solve_schedules_are_bit_identical(monkeypatch):
     Xs = rng.uniform(-1, 1, (d, ns))
     g = GPR(X, y, 0.1, cov_func(sqrexp, l=0.7))
     out = {}
-    for mode in ("right", "left"):
+    for mode in ("right", "left", "2", "3"):              # "2": groups {0,1},{2,3}; "3": {0,1,2},{3}
         monkeypatch.setenv("GPRC_SOLVE", mode)
         out[mode] = (g.predict(Xs), g.predict(Xs, pointwise_var=False)[1])
-    assert np.array_equal(out["left"][0], out["right"][0]) and np.array_equal(out["left"][1], out["right"][1])
+    for mode in ("left", "2", "3"):
+        assert np.array_equal(out[mode][0], out["right"][0]) and np.array_equal(out[mode][1], out["right"][1]), mode
     ref = orc.gpr_fit(orc.SQREXP, [0.7], X, y, 0.1)
     mean, var = orc.gpr_predict(orc.SQREXP, [0.7], X, ref["L"], ref["alpha"], Xs)
     assert nerr(out["left"][0][:, 0], mean) <= TOL and nerr(out["left"][0][:, 1], var) <= TOL
