@@ -83,6 +83,7 @@ PROTOTYPES = {
     "gprc_winv_size": (_i64, [_i64]),
     "gprc_dev_fill_panel": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _i64, C.c_double, _vp, _i64]),
     "gprc_dev_factor_panel": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "gprc_dev_factor_all": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "gprc_dev_update_trailing": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64]),
     "gprc_trsv_work_size": (_i64, [_i64]),
     "gprc_dev_trsv": (C.c_int, [_vp, _vp, _vp, _i64, _vp, C.c_int, _vp]),
@@ -171,7 +172,7 @@ def device_count() -> int:
 
 
 PROF_KINDS = ["fill", "potf2_inv", "trsm_panel", "gemm_inner_k128", "trailing_update", "solve_update_k512", "trsv",
-              "row_reduce", "cov_syrk", "deriv_rowsum", "jacobi_sweep", "solve_left"]
+              "row_reduce", "cov_syrk", "deriv_rowsum", "jacobi_sweep", "solve_left", "trailing_left"]
 
 
 def prof_summary():

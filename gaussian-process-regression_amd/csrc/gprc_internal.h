@@ -42,7 +42,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 // ---- in-library event profiler (bench.py's live roofline numbers) ---------------------------------
 enum ProfKind { PK_FILL = 0, PK_POTF2 = 1, PK_TRSM_PANEL = 2, PK_GEMM_INNER = 3, PK_TRAILING = 4, PK_SOLVE_UPDATE = 5,
-                PK_TRSV = 6, PK_ROWREDUCE = 7, PK_COV_SYRK = 8, PK_DERIV = 9, PK_JACOBI = 10, PK_SOLVE_LEFT = 11, PK_COUNT = 12 };
+                PK_TRSV = 6, PK_ROWREDUCE = 7, PK_COV_SYRK = 8, PK_DERIV = 9, PK_JACOBI = 10, PK_SOLVE_LEFT = 11, PK_TRAILING_LEFT = 12, PK_COUNT = 13 };
 bool prof_enabled();
 void prof_begin(hipStream_t s, int kind);
 void prof_end(hipStream_t s, int kind, double flops, double bytes);
@@ -91,6 +91,7 @@ int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t
                            int64_t q_stride);
 
 // ---- launchers (kernels_vec.hip) ---------------------------------------------------------------
+int launch_trailing_left(hipStream_t s, double* packed, int64_t n_pad, int64_t q_begin, int64_t q_end);
 int launch_trsv(hipStream_t s, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose, double* work);
 int64_t rowreduce_splits(int64_t cols);
 int launch_row_reduce(hipStream_t s, const double* vt, int64_t ld, int64_t rows, int64_t cols, const double* w, double* out,

@@ -329,10 +329,11 @@ __device__ __forceinline__ void dma_ktile(const double* Ag, int64_t lda, const d
   }
 }
 
-// SEG: the B strip is rows [brow, brow + 128) of the PACKED factor across its first K columns (B = packed base,
-// ldb = n_pad): every NB columns the strip moves to the next panel, with that panel's own leading dimension.
+// Where k-tile kt of an operand strip lives (this lane's 16 bytes of k-slice `wave`).  Plain: a column-major strip with
+// one leading dimension.  SEG: the strip is rows [brow, brow + 128) of the PACKED factor across its first K columns
+// (B = packed base, ldb = n_pad): every NB columns it moves to the next panel, with that panel's own leading dimension.
 template <bool SEG>
-__device__ __forceinline__ const double* b_ktile(const double* B, int64_t ldb, int64_t brow, int kt, int lane, int wave, int64_t& ld) {
+__device__ __forceinline__ const double* strip_ktile(const double* B, int64_t ldb, int64_t brow, int kt, int lane, int wave, int64_t& ld) {
   if constexpr (SEG) {
     const int pp = kt / (NB / 16);                    // panel that holds k-tile kt
     ld = panel_ld(ldb, pp);
@@ -343,9 +344,9 @@ __device__ __forceinline__ const double* b_ktile(const double* B, int64_t ldb, i
   }
 }
 
-template <bool SET, bool SEG = false>
+template <bool SET, bool SEG = false, bool SEGA = false>
 __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
-                                              int64_t ldb, int K, double* smem, int64_t brow = 0) {
+                                              int64_t ldb, int K, double* smem, int64_t brow = 0, int64_t arow = 0) {
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -365,9 +366,9 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
 #pragma unroll
       for (int m = 0; m < 4; ++m) acc[m][n][r] = SET ? 0.0 : Cw[m * 16 + (int64_t)(n * 16 + 4 * r) * ldc];
 
-  const double* Ag = A + 2 * lane + (int64_t)wave * lda;  // this lane's 16 bytes of k-slice `wave`
-  int64_t ldbk;
-  const double* Bg = b_ktile<SEG>(B, ldb, brow, 0, lane, wave, ldbk);
+  int64_t ldak, ldbk;
+  const double* Ag = strip_ktile<SEGA>(A, lda, arow, 0, lane, wave, ldak);  // this lane's 16 bytes of k-slice `wave`
+  const double* Bg = strip_ktile<SEG>(B, ldb, brow, 0, lane, wave, ldbk);
   const int srow = wave * G_LDT;                          // LDS row of that slice (wave-uniform)
   const int foff = fr + fk * G_LDT;                       // this lane's MFMA operand element
 
@@ -381,16 +382,17 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
   // so a DMA has 64 MFMAs (4096 cycles) to land, as before.
   constexpr int LGKM0 = 0xC07F;  // s_waitcnt lgkmcnt(0), vmcnt/expcnt untouched
   const int KT = K / G_KB;
-  dma_ktile(Ag, lda, Bg, ldbk, As + srow, Bs + srow);
+  dma_ktile(Ag, ldak, Bg, ldbk, As + srow, Bs + srow);
   // vmcnt(0) through the BUILTIN, not inline asm, so that the compiler's waitcnt pass knows the C-tile loads
   // above have completed and does not re-wait vmcnt(0) (draining fresh DMAs) inside the loop.  0x0F70 = vmcnt(0).
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   if (KT > 1) {
-    Bg = b_ktile<SEG>(B, ldb, brow, 1, lane, wave, ldbk);
-    dma_ktile(Ag + (int64_t)G_KB * lda, lda, Bg, ldbk, As + G_BUF + srow, Bs + G_BUF + srow);
+    Ag = strip_ktile<SEGA>(A, lda, arow, 1, lane, wave, ldak);
+    Bg = strip_ktile<SEG>(B, ldb, brow, 1, lane, wave, ldbk);
+    dma_ktile(Ag, ldak, Bg, ldbk, As + G_BUF + srow, Bs + G_BUF + srow);
   }
-  Ag += (int64_t)2 * G_KB * lda;  // next tile to request: kt + 2
+  if constexpr (!SEGA) Ag = A + 2 * lane + (int64_t)(2 * G_KB + wave) * lda;  // next tile to request: kt + 2
   if constexpr (!SEG) Bg = B + 2 * lane + (int64_t)(2 * G_KB + wave) * ldb;
   double a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
   read_ops(As + wr * 64 + foff, Bs + wc * 64 + foff, 0, a0, b0);
@@ -416,9 +418,10 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 has landed (this wave's share)
       __syncthreads();                                   // ... everyone's share; and buffer `cur` is drained
       if (kt + 2 < KT) {
-        if constexpr (SEG) Bg = b_ktile<true>(B, ldb, brow, kt + 2, lane, wave, ldbk);
-        dma_ktile(Ag, lda, Bg, ldbk, As + cur + srow, Bs + cur + srow);
-        Ag += (int64_t)G_KB * lda;
+        if constexpr (SEGA) Ag = strip_ktile<true>(A, lda, arow, kt + 2, lane, wave, ldak);
+        if constexpr (SEG) Bg = strip_ktile<true>(B, ldb, brow, kt + 2, lane, wave, ldbk);
+        dma_ktile(Ag, ldak, Bg, ldbk, As + cur + srow, Bs + cur + srow);
+        if constexpr (!SEGA) Ag += (int64_t)G_KB * lda;
         if constexpr (!SEG) Bg += (int64_t)G_KB * ldb;
       }
       read_ops(An, Bn, 0, a0, b0);
@@ -534,6 +537,41 @@ __global__ __launch_bounds__(256, 2) void solve_left_kernel(double* vt, int64_t 
   gemm_tile_128<false, true>(vt + (int64_t)tr * 128 + col * ldv, ldv, vt + (int64_t)tr * 128, ldv, packed, n_pad, j * NB, smem, col);
 }
 
+
+// Left-looking form of the trailing update for a GROUP of target panels [q_begin, q_begin + n_targets): every lower
+// tile of those panels receives the contributions of ALL panels before the group in one pass,
+//   A[R.., C..] -= L[R.., 0 : K] * L[C.., 0 : K]^T,   K = q_begin NB,
+// both operand strips walking through the packed panels.  Same products, same order as the right-looking passes
+// p = 0 .. q_begin - 1 (k ascending from the loaded C value): bit-identical, one C load/store and one tile prologue
+// instead of q_begin.
+__global__ __launch_bounds__(256, 2) void trailing_left_kernel(double* packed, int64_t n_pad, int q_begin, int n_targets, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int P = (int)(n_pad / NB);
+  constexpr int DIAG_TILES = TPP * (TPP + 1) / 2;
+  int id = (int)xcd_remap(blockIdx.x, (unsigned)ntiles);
+  int q = q_begin, s = 0;
+  for (; s < n_targets; ++s, ++q) {
+    const int tq = TPP * TPP * (P - q) - TPP * (TPP - 1) / 2;
+    if (id < tq) break;
+    id -= tq;
+  }
+  if (s >= n_targets) return;
+  int tr, tc;
+  if (id < DIAG_TILES) {
+    tr = 0;
+    while ((tr + 1) * (tr + 2) / 2 <= id) ++tr;
+    tc = id - tr * (tr + 1) / 2;
+  } else {
+    tr = TPP + (id - DIAG_TILES) / TPP;
+    tc = (id - DIAG_TILES) % TPP;
+  }
+  const int64_t ldq = panel_ld(n_pad, q);
+  double* Cq = packed + panel_offset(n_pad, q);
+  const int64_t row = (int64_t)q * NB + (int64_t)tr * 128, col = (int64_t)q * NB + (int64_t)tc * 128;
+  gemm_tile_128<false, true, true>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, packed, n_pad, packed, n_pad, q_begin * NB, smem,
+                                   col, row);
+}
+
 }  // namespace
 
 int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* info_dev, int col0) {
@@ -569,6 +607,7 @@ static int ensure_gemm_attrs() {
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_left_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_left_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   if (dev >= 0 && dev < MAX_DEVICES) done[dev] = true;
   return 0;
 }
@@ -639,6 +678,29 @@ int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t
   const unsigned grid = (unsigned)((pg > 0 && tiles > pg) ? pg : tiles);
   hipLaunchKernelGGL(trailing_kernel, dim3(grid), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)p,
                      (int)q_begin, (int)q_stride, (int)nt, (int)tiles);
+  GPRC_LAUNCH_CHECK();
+  return 0;
+}
+
+// left-looking update of target panels [q_begin, q_end) with every panel before q_begin
+int launch_trailing_left(hipStream_t s, double* packed, int64_t n_pad, int64_t q_begin, int64_t q_end) {
+  const int64_t P = n_pad / NB;
+  if (q_end > P) q_end = P;
+  if (q_begin <= 0 || q_begin >= q_end) return 0;
+  GPRC_TRY(ensure_gemm_attrs());
+  int64_t tiles = 0;
+  double fl = 0.0, by = 0.0;
+  const double K = (double)q_begin * NB;
+  for (int64_t q = q_begin; q < q_end; ++q) {
+    tiles += (int64_t)TPP * TPP * (P - q) - TPP * (TPP - 1) / 2;
+    const double rows = (double)(n_pad - q * NB);
+    const double elems = rows * NB - 0.5 * NB * (double)(NB - 1);
+    fl += 2.0 * elems * K;
+    by += 8.0 * (2.0 * elems + rows * K);
+  }
+  ProfScope ps(s, PK_TRAILING_LEFT, fl, by);
+  hipLaunchKernelGGL(trailing_left_kernel, dim3((unsigned)tiles), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)q_begin,
+                     (int)(q_end - q_begin), (int)tiles);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

@@ -231,6 +231,11 @@ class HipOps:
     def factor_panel(self, packed, p, winv, info, side):
         nat.check(self.L.gprc_dev_factor_panel(self._ctx(side), packed.data_ptr(), self.geom.n_pad, p, winv.data_ptr(), info.data_ptr()))
 
+    def factor_all(self, packed, winv, info):
+        """Every panel on this one GPU (no exchange): the native grouped left-looking sweep, bit-identical to the
+        factor_panel / update_trailing loop."""
+        nat.check(self.L.gprc_dev_factor_all(self._ctx(False), packed.data_ptr(), self.geom.n_pad, winv.data_ptr(), info.data_ptr()))
+
     def update_trailing(self, packed, p, q0, q1, stride, side):
         if q0 < q1:
             nat.check(self.L.gprc_dev_update_trailing(self._ctx(side), packed.data_ptr(), self.geom.n_pad, p, q0, q1, stride))
@@ -305,6 +310,10 @@ class DistributedGPR:
             self.info.zero_() if hasattr(self.info, "zero_") else self.info.fill(0)
             for p in range(rank, P, G):                       # F1: own panels only, no communication
                 ops.fill_panel(X, self.packed, p)
+        if G == 1 and not self.lookahead and isinstance(comm, SingleComm) and hasattr(ops, "factor_all"):
+            with ops.on(False):                               # one rank, nothing to exchange: the whole sweep natively
+                ops.factor_all(self.packed, self.winv, self.info)
+            return self._finish_fit(y_pad)
         ops.fork_side()
         if rank == 0:
             with ops.on(True):
@@ -334,6 +343,10 @@ class DistributedGPR:
                     ops.update_trailing(self.packed, p, q0, P, G, False)
                 self._bcast_panel(p + 1)                      # overlaps the update above
         ops.join_side()
+        return self._finish_fit(y_pad)
+
+    def _finish_fit(self, y_pad):
+        ops, comm = self.ops, self.comm
         self.info_value = comm.min_positive(ops.read_info(self.info))
         if self.info_value != 0:
             return self.info_value

@@ -179,6 +179,10 @@ GPRC_API int gprc_dev_fill_panel(gprc_ctx* ctx, int kernel, const double* params
 /* factor panel p in place (diagonal blocks in LDS, panel solves, in-panel updates); info_dev is a
  * device int the first non-PD column (1-based) is written to (must be zeroed by the caller) */
 GPRC_API int gprc_dev_factor_panel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev);
+/* All panels of an already filled packed matrix on ONE GPU, asynchronously on the context's stream (the one-rank form of
+ * the factor_panel / update_trailing sweep): grouped left-looking schedule, results bit-identical to that sweep.
+ * info_dev: one device int, zeroed by the caller, receives LAPACK's info (first non-PD leading minor) if any. */
+GPRC_API int gprc_dev_factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev);
 /* trailing update of panels q = q_begin, q_begin + q_stride, ... < q_end with factored panel p */
 GPRC_API int gprc_dev_update_trailing(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, int64_t q_begin,
                              int64_t q_end, int64_t q_stride);

@@ -399,3 +399,23 @@ def test_left_and_right_looking_solve_schedules_are_bit_identical(monkeypatch):
     ref = orc.gpr_fit(orc.SQREXP, [0.7], X, y, 0.1)
     mean, var = orc.gpr_predict(orc.SQREXP, [0.7], X, ref["L"], ref["alpha"], Xs)
     assert nerr(out["left"][0][:, 0], mean) <= TOL and nerr(out["left"][0][:, 1], var) <= TOL
+
+
+def test_factor_schedules_are_bit_identical(monkeypatch):
+    """The one-GPU Cholesky sweep groups panels and applies all earlier panels to a group in one left-looking pass; any
+    grouping -- one group (= right-looking), one panel per group (= left-looking), mixed -- gives the same bits."""
+    rng = np.random.default_rng(29)
+    d, n = 3, 2300                                 # 5 panels; lower tiles per panel: 74, 58, 42, 26, 10
+    X = rng.uniform(-1, 1, (d, n))
+    y = rng.normal(size=n)
+    res = {}
+    for mode in ("right", "1", "60", "100"):       # "1": every panel its own group; "60": {0},{1,2},{3,4}; "100": {0,1},{2,3,4}
+        monkeypatch.setenv("GPRC_FACTOR", mode)
+        g = GPR(X, y, 0.1, cov_func(rationalquadratic, l=0.8, alpha=1.5))
+        res[mode] = (g.L.copy(), g.alpha.copy(), g.logp)
+        g.close()
+    for mode in ("1", "60", "100"):
+        assert np.array_equal(res[mode][0], res["right"][0]) and np.array_equal(res[mode][1], res["right"][1]), mode
+        assert res[mode][2] == res["right"][2]
+    ref = orc.gpr_fit(orc.RATQUAD, [0.8, 1.5], X, y, 0.1)
+    assert nerr(res["1"][0], ref["L"]) <= TOL and nerr(res["1"][1], ref["alpha"]) <= TOL
