@@ -315,13 +315,13 @@ int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* 
 //   left-looking:  before a GROUP of G panels is solved, subtract the contributions of ALL earlier panels from the
 //                  group's columns in one pass (K = p NB), the C tile staying in the accumulators -- one C load/store
 //                  and one tile prologue instead of p; inside the group the panels update each other right-looking.
-// G is the smallest group that gives a pass (m_pad / 128) * 4 G >= 1024 tiles (two workgroups on each of 256 CUs, twice
-// over); G >= P degenerates to plain right-looking.  GPRC_SOLVE=right forces that, =left forces G = 1, =<n> G = n.
+// G is the smallest group that gives a pass (m_pad / 128) * 4 G >= 4096 tiles (eight generations of two workgroups on
+// each of 256 CUs: the partially filled last generation of long tiles stays cheap); G >= P degenerates to plain right-looking.  GPRC_SOLVE=right forces that, =left forces G = 1, =<n> G = n.
 int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt, int64_t ldv, int64_t m_pad) {
   hipStream_t s = ctx->stream;
   const int64_t P = n_pad / NB;
   const char* mode = std::getenv("GPRC_SOLVE");
-  int64_t G = (1024 + (m_pad / 128) * (NB / NBI) - 1) / ((m_pad / 128) * (NB / NBI));
+  int64_t G = (4096 + (m_pad / 128) * (NB / NBI) - 1) / ((m_pad / 128) * (NB / NBI));
   if (mode && std::strcmp(mode, "left") == 0) G = 1;
   else if (mode && std::atoi(mode) > 0) G = std::atoi(mode);  // an explicit group size
   if ((mode && std::strcmp(mode, "right") == 0) || G > P) G = P;
