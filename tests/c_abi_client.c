@@ -75,6 +75,36 @@ int main(void) {
   CHECK(gprc_kernel_matrix(ctx, GPRC_SQREXP, &l, 1, A, 2, 3, A, 3, K, 5) == 0, "kernel_matrix");
   CHECK(K[0] == 1.0 && fabs(K[1] - exp(-0.5)) < 1e-16 && fabs(K[5 + 2] - exp(-1.0)) < 1e-16 && K[3] == -7.0, "kernel_matrix values / ld");
 
+
+  /* fit(): objective and gradient (R/fit.R:117-139) on three well separated points */
+  const double Xf[3] = {0.0, 1.5, 3.5}, yf[3] = {0.3, -0.2, 0.9}, lf = 0.4;
+  double lml = 0.0, grad[2] = {0.0, 0.0};
+  CHECK(gprc_gpr_log_marginal(ctx, GPRC_SQREXP, &lf, 1, Xf, 1, 3, yf, 0.1, &lml) == 0 && lml < 0.0 && lml > -10.0, "log_marginal %g", lml);
+  CHECK(gprc_fit_gradient(ctx, GPRC_SQREXP, &lf, 1, Xf, 1, 3, yf, grad) == 0 && isfinite(grad[0]), "fit_gradient %g", grad[0]);
+  const double same[3] = {1.0, 1.0, 2.0};
+  rc = gprc_fit_gradient(ctx, GPRC_SQREXP, &lf, 1, same, 1, 3, yf, grad);
+  CHECK(rc > 0, "fit_gradient on a singular K returns info, rc=%d", rc);
+
+  /* multivariate_normal (R/GPRclass.R:360-370): Cholesky branch on diag(4, 9), eigen branch on a rank-1 matrix */
+  const double mu[2] = {1.0, -1.0}, cov1[4] = {4.0, 0.0, 0.0, 9.0}, cov2[4] = {1.0, 1.0, 1.0, 1.0}, Z[4] = {1.0, 0.5, -1.0, 2.0};
+  double draws[4], vals[2], vecs[4];
+  int method = 0, sweeps = 0;
+  CHECK(gprc_mvn_sample(ctx, cov1, 2, 2, mu, 1e-6, Z, 2, draws, &method) == 0 && method == 1, "mvn chol method=%d", method);
+  CHECK(fabs(draws[0] - 3.0) < 1e-14 && fabs(draws[1] - 0.5) < 1e-14 && fabs(draws[2] + 1.0) < 1e-14 && fabs(draws[3] - 5.0) < 1e-14, "mvn chol draws");
+  CHECK(gprc_mvn_sample(ctx, cov2, 2, 2, mu, 1e-6, Z, 2, draws, &method) == 0 && method == 2, "mvn eigen method=%d", method);
+  CHECK(fabs((draws[0] - mu[0]) - (draws[1] - mu[1])) < 1e-14, "rank-1 covariance: both coordinates move together");
+  CHECK(gprc_sym_eigen(ctx, cov2, 2, 2, vals, vecs, &sweeps) == 0 && fabs(vals[0] - 2.0) < 1e-14 && fabs(vals[1]) < 1e-14, "sym_eigen %g %g", vals[0], vals[1]);
+  const double neg[4] = {1.0, 0.0, 0.0, -1.0};
+  CHECK(gprc_mvn_sample(ctx, neg, 2, 2, mu, 1e-6, Z, 2, draws, &method) == GPRC_ERR_NOT_PD, "indefinite covariance is refused");
+
+  /* combine_all (R/simulation.R:338-349): last axis fastest */
+  const double axes[5] = {0.0, 1.0, 10.0, 20.0, 30.0};
+  const int64_t lens[2] = {2, 3};
+  double grid[12];
+  CHECK(gprc_combine_all(ctx, axes, lens, 2, grid) == 0, "combine_all");
+  CHECK(grid[0] == 0.0 && grid[1] == 10.0 && grid[2] == 0.0 && grid[3] == 20.0 && grid[6] == 1.0 && grid[7] == 10.0 && grid[11] == 30.0, "combine_all order");
+  CHECK(gprc_ctx_trim(ctx) == 0, "ctx_trim");
+
   gprc_ctx_destroy(ctx);
   printf(fails ? "c_abi_client: %d FAILED\n" : "c_abi_client: all checks passed\n", fails);
   return fails ? 1 : 0;
