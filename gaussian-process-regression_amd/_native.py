@@ -83,6 +83,7 @@ PROTOTYPES = {
     "gprc_winv_size": (_i64, [_i64]),
     "gprc_dev_fill_panel": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _i64, C.c_double, _vp, _i64]),
     "gprc_dev_factor_panel": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "gprc_dev_factor_subpanel": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _vp]),
     "gprc_dev_factor_all": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "gprc_dev_update_trailing": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64]),
     "gprc_trsv_work_size": (_i64, [_i64]),

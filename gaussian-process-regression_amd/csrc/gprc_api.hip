@@ -255,21 +255,29 @@ int use_device(const gprc_ctx* ctx) {
 }
 
 // ---- factorisation of all panels of a packed matrix (single GPU) ------------------------------
-int factor_panel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev) {
+// 128-column sub-step j of panel p: factor + invert the diagonal block, solve the rows below it, update the rest of the
+// panel.  After it, columns [128 j, 128 (j+1)) of the panel are final (what the pipelined broadcast relies on).
+// part: 1 = factor + solve (the columns become final), 2 = update of the rest of the panel, 0 = both.
+int factor_subpanel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, int j, int part, double* winv, int* info_dev) {
   hipStream_t s = ctx->stream;
   const int64_t ld = panel_ld(n_pad, p);
   double* pan = packed + panel_offset(n_pad, p);
-  for (int j = 0; j < NB / NBI; ++j) {
-    const int64_t cj = (int64_t)j * NBI;
-    double* wblk = winv + (p * (NB / NBI) + j) * NBI * NBI;
+  const int64_t cj = (int64_t)j * NBI;
+  double* wblk = winv + (p * (NB / NBI) + j) * NBI * NBI;
+  const int64_t below = ld - cj - NBI;
+  double* Lcol = pan + (cj + NBI) + cj * ld;
+  if (part != 2) {
     GPRC_TRY(launch_potf2_inv(s, pan + cj + cj * ld, ld, wblk, info_dev, (int)(p * NB + cj)));
-    const int64_t below = ld - cj - NBI;
-    if (below <= 0) continue;
-    double* Lcol = pan + (cj + NBI) + cj * ld;
-    GPRC_TRY(launch_trsm_panel(s, Lcol, ld, below, wblk));
-    const int64_t rest = NB - cj - NBI;  // remaining columns of this panel
-    if (rest > 0) GPRC_TRY(launch_gemm_nt(s, pan + (cj + NBI) + (cj + NBI) * ld, ld, Lcol, ld, Lcol, ld, below, rest, NBI, 1, PK_GEMM_INNER));
+    if (below > 0) GPRC_TRY(launch_trsm_panel(s, Lcol, ld, below, wblk));
   }
+  const int64_t rest = NB - cj - NBI;  // remaining columns of this panel
+  if (part != 1 && below > 0 && rest > 0)
+    GPRC_TRY(launch_gemm_nt(s, pan + (cj + NBI) + (cj + NBI) * ld, ld, Lcol, ld, Lcol, ld, below, rest, NBI, 1, PK_GEMM_INNER));
+  return 0;
+}
+
+int factor_panel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev) {
+  for (int j = 0; j < NB / NBI; ++j) GPRC_TRY(factor_subpanel(ctx, packed, n_pad, p, j, 0, winv, info_dev));
   return 0;
 }
 
@@ -1052,6 +1060,14 @@ int gprc_dev_factor_panel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t 
   return factor_panel(ctx, packed, n_pad, p, winv, info_dev);
 }
 
+int gprc_dev_factor_subpanel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, int j, int part, double* winv, int* info_dev) {
+  GPRC_TRY(use_device(ctx));
+  if (n_pad % NB || p < 0 || p >= n_pad / NB || j < 0 || j >= NB / NBI || part < 0 || part > 2 || !info_dev) {
+    set_error("factor_subpanel: bad arguments");
+    return GPRC_ERR_ARG;
+  }
+  return factor_subpanel(ctx, packed, n_pad, p, j, part, winv, info_dev);
+}
 int gprc_dev_factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev) {
   GPRC_TRY(use_device(ctx));
   if (!packed || !winv || !info_dev || n_pad <= 0 || n_pad % NB) { set_error("dev_factor_all: bad arguments"); return GPRC_ERR_ARG; }

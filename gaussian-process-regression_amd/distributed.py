@@ -48,6 +48,11 @@ class Geometry:
     def winv_slice(self, p):
         return slice(p * self.winv_per_panel, (p + 1) * self.winv_per_panel)
 
+    def panel_part_slice(self, p, j):
+        """Columns [128 j, 128 (j+1)) of panel p: contiguous in the packed buffer (column-major, ld = n_pad - p NB)."""
+        ld = self.n_pad - p * self.NB
+        return slice(self.offsets[p] + j * 128 * ld, self.offsets[p] + (j + 1) * 128 * ld)
+
 
 class SingleComm:
     """world_size 1: no exchange."""
@@ -182,6 +187,7 @@ class HipOps:
         # thousands of queued workgroups of the trailing update that runs beside it
         prio = int(os.environ.get("GPRC_SIDE_PRIORITY", "-1"))
         self.side_stream = torch.cuda.Stream(device=self.device, priority=prio)
+        self.comm_stream = torch.cuda.Stream(device=self.device, priority=prio)   # where the panel broadcasts are posted
         self.ctx_main = nat.Context(device, self.main_stream.cuda_stream)
         self.ctx_side = nat.Context(device, self.side_stream.cuda_stream)
         self.kernel_id = int(kernel_id)
@@ -209,15 +215,26 @@ class HipOps:
         with self.torch.cuda.stream(self.side_stream if side else self.main_stream):
             yield
 
+    @contextmanager
+    def on_comm(self):
+        with self.torch.cuda.stream(self.comm_stream):
+            yield
+
     def fork_side(self):
         self.side_stream.wait_stream(self.main_stream)
 
+    def comm_after_side(self):
+        """The communication stream waits for everything queued on the side stream so far."""
+        self.comm_stream.wait_stream(self.side_stream)
+
     def join_side(self):
         self.main_stream.wait_stream(self.side_stream)
+        self.main_stream.wait_stream(self.comm_stream)
 
     def synchronize(self):
         self.main_stream.synchronize()
         self.side_stream.synchronize()
+        self.comm_stream.synchronize()
 
     def _ctx(self, side):
         return (self.ctx_side if side else self.ctx_main).handle
@@ -230,6 +247,10 @@ class HipOps:
 
     def factor_panel(self, packed, p, winv, info, side):
         nat.check(self.L.gprc_dev_factor_panel(self._ctx(side), packed.data_ptr(), self.geom.n_pad, p, winv.data_ptr(), info.data_ptr()))
+
+    def factor_subpanel(self, packed, p, j, part, winv, info, side):
+        nat.check(self.L.gprc_dev_factor_subpanel(self._ctx(side), packed.data_ptr(), self.geom.n_pad, p, j, part, winv.data_ptr(),
+                                                  info.data_ptr()))
 
     def factor_all(self, packed, winv, info):
         """Every panel on this one GPU (no exchange): the native grouped left-looking sweep, bit-identical to the
@@ -281,7 +302,6 @@ class DistributedGPR:
     """The predict step of BASELINE.json on G ranks: fit (F1-F3) + pointwise predict (P1-P3)."""
 
     def __init__(self, ops, comm, lookahead=None):
-        import os
         self.ops, self.comm = ops, comm
         # Look-ahead pays when there is a broadcast to hide (world > 1).  On ONE GPU the side-stream panel chain
         # only competes with the trailing update for CUs (measured: potf2 0.17 -> 0.42 ms under contention, step
@@ -290,6 +310,9 @@ class DistributedGPR:
         if lookahead is None:
             lookahead = (comm.world > 1) if env is None else (env == "1")
         self.lookahead = bool(lookahead)
+        # pipelined panel exchange: the owner broadcasts each 128-column quarter of a panel as soon as it is final,
+        # while it is still factoring the rest (GPRC_PIPE_BCAST=0: factor the whole panel, then one broadcast)
+        self.pipeline = os.environ.get("GPRC_PIPE_BCAST", "1") != "0" and hasattr(ops, "factor_subpanel")
         g = ops.geom
         self.geom = g
         self.packed = ops.zeros(g.packed_size)
@@ -315,10 +338,7 @@ class DistributedGPR:
                 ops.factor_all(self.packed, self.winv, self.info)
             return self._finish_fit(y_pad)
         ops.fork_side()
-        if rank == 0:
-            with ops.on(True):
-                ops.factor_panel(self.packed, 0, self.winv, self.info, True)
-        self._bcast_panel(0)
+        self._factor_and_share(0)
         for p in range(P):                                    # F2: right-looking, one panel per step
             ops.join_side()                                   # panel p factored (owner) / received (others)
             if p + 1 < P:
@@ -327,23 +347,45 @@ class DistributedGPR:
                     with ops.on(False):
                         ops.update_trailing(self.packed, p, p + 1, P, G, False)
                     ops.fork_side()
-                    with ops.on(True):
-                        ops.factor_panel(self.packed, p + 1, self.winv, self.info, True)
-                    self._bcast_panel(p + 1)
+                    self._factor_and_share(p + 1)
                     continue
                 if rank == nxt:
                     ops.fork_side()                           # look-ahead: panel p+1 first, on the side stream
                     with ops.on(True):
                         ops.update_trailing(self.packed, p, p + 1, p + 2, 1, True)
-                        ops.factor_panel(self.packed, p + 1, self.winv, self.info, True)
                     q0 = p + 1 + G
                 else:
                     q0 = owned_after(p, rank, G)
+                self._factor_and_share(p + 1)                 # owner: side stream; everybody: broadcasts on the comm stream
                 with ops.on(False):
-                    ops.update_trailing(self.packed, p, q0, P, G, False)
-                self._bcast_panel(p + 1)                      # overlaps the update above
+                    ops.update_trailing(self.packed, p, q0, P, G, False)   # runs beside the factorisation and the exchange
         ops.join_side()
         return self._finish_fit(y_pad)
+
+    def _factor_and_share(self, p):
+        """Panel p has received every update on its owner: factor it there (side stream) and replicate it (comm stream).
+        Pipelined form: sub-step j makes the columns [128 j, 128 (j+1)) final; their broadcast is posted at once and
+        runs while the owner updates and factors the rest of the panel."""
+        ops, comm, g = self.ops, self.comm, self.geom
+        src = p % comm.world
+        exchange = comm.world > 1 or isinstance(comm, TorchComm)
+        if not (self.pipeline and exchange):
+            if comm.rank == src:
+                with ops.on(True):
+                    ops.factor_panel(self.packed, p, self.winv, self.info, True)
+            self._bcast_panel(p)
+            return
+        for j in range(g.NB // 128):
+            if comm.rank == src:
+                with ops.on(True):
+                    ops.factor_subpanel(self.packed, p, j, 1, self.winv, self.info, True)   # factor + solve: columns final
+                ops.comm_after_side()
+                with ops.on(True):
+                    ops.factor_subpanel(self.packed, p, j, 2, self.winv, self.info, True)   # update the rest of the panel
+            with ops.on_comm():
+                comm.broadcast(self.packed[g.panel_part_slice(p, j)], src)
+        with ops.on_comm():
+            comm.broadcast(self.winv[g.winv_slice(p)], src)   # the four inverses were complete before the last quarter left
 
     def _finish_fit(self, y_pad):
         ops, comm = self.ops, self.comm
@@ -362,7 +404,9 @@ class DistributedGPR:
             return
         g = self.geom
         src = p % self.comm.world
-        with self.ops.on(True):
+        if self.comm.rank == src:
+            self.ops.comm_after_side()                        # the panel is complete on the side stream
+        with self.ops.on_comm():
             self.comm.broadcast(self.packed[g.panel_slice(p)], src)
             self.comm.broadcast(self.winv[g.winv_slice(p)], src)
 

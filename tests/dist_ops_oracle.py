@@ -37,6 +37,13 @@ class OracleOps:
     def on(self, side):
         yield
 
+    @contextmanager
+    def on_comm(self):
+        yield
+
+    def comm_after_side(self):
+        self.log.append(("comm_after_side",))
+
     def fork_side(self):
         self.log.append(("fork",))
 
@@ -95,6 +102,27 @@ class OracleOps:
             blk = np.tril(D[j * 128:(j + 1) * 128, j * 128:(j + 1) * 128])
             w[j] = (np.linalg.inv(blk) if not inf else np.eye(128)).T  # stored column-major
         self.log.append(("factor", p, bool(side)))
+
+    def factor_subpanel(self, packed, p, j, part, winv, info, side):
+        """Sub-step j of panel p: part 1 = factor the 128 x 128 diagonal block, solve the rows below it (those columns
+        are then final); part 2 = update the remaining columns of the panel with them."""
+        g = self.geom
+        pan = self._panel(packed, p)
+        c0, c1 = 128 * j, 128 * (j + 1)
+        if part in (0, 1):
+            D, inf = orc.potrf_lower(pan[c0:c1, c0:c1])
+            if inf and int(info[0]) == 0:
+                info[0] = p * g.NB + c0 + inf
+            pan[c0:c1, c0:c1] = D
+            if not inf:
+                pan[c1:, c0:c1] = sl.solve_triangular(np.tril(D), pan[c1:, c0:c1].T, lower=True).T
+            w = winv.numpy()[g.winv_slice(p)].reshape(g.NB // 128, 128, 128)
+            w[j] = (np.linalg.inv(np.tril(D)) if not inf else np.eye(128)).T  # stored column-major
+            if j == g.NB // 128 - 1:
+                self.log.append(("factor", p, bool(side)))
+        if part in (0, 2) and c1 < g.NB:
+            Lcol = pan[c1:, c0:c1]
+            pan[c1:, c1:g.NB] -= Lcol @ Lcol[: g.NB - c1, :].T
 
     def update_trailing(self, packed, p, q0, q1, stride, side):
         g = self.geom

@@ -36,6 +36,9 @@ def _problem(n, d, ns, seed=11):
 
 def _worker(rank, world, port, n, d, ns, out_dir, bcast="broadcast"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if bcast == "whole_panel":                               # the unpipelined exchange: factor the panel, then one broadcast
+        os.environ["GPRC_PIPE_BCAST"] = "0"
+        bcast = "broadcast"
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import gprc_amd  # noqa: F401
@@ -70,7 +73,8 @@ def _worker(rank, world, port, n, d, ns, out_dir, bcast="broadcast"):
 
 
 @pytest.mark.parametrize("world,n,bcast", [(2, 1300, "broadcast"), (3, 2100, "broadcast"), (2, 1300, "scatter_allgather"),
-                                           (4, 2100, "scatter_allgather"), (2, 1300, "auto"), (4, 700, "broadcast")])
+                                           (4, 2100, "scatter_allgather"), (2, 1300, "auto"), (4, 700, "broadcast"),
+                                           (2, 1300, "whole_panel")])
 def test_block_cyclic_fit_and_sliced_predict(tmp_path, world, n, bcast):
     """bcast: how a factored panel reaches the other ranks -- one rooted broadcast, or scatter + all-gather (the
     large-message form for point-to-point links); "auto" runs the calibration that picks one.  Same results."""
@@ -103,6 +107,9 @@ def test_block_cyclic_fit_and_sliced_predict(tmp_path, world, n, bcast):
             idx_upd = log.index(("update", p, p + 1, True))
             rest = [i for i, e in enumerate(log) if e[0] == "update" and e[1] == p and e[2] > p + 1]
             assert idx_upd < idx_fac and all(i > idx_fac for i in rest)
+            if bcast != "whole_panel":                        # pipelined exchange: a hand-over to the comm stream per quarter
+                # (the "factor" entry is logged by the last quarter's factor step; its hand-over follows immediately)
+                assert sum(1 for e in log[idx_upd:idx_fac + 2] if e == ("comm_after_side",)) == 4
     # every panel is updated by every earlier panel exactly once, somewhere
     ups = sorted((e[1], e[2]) for o in outs for e in map(eval, o["log"]) if e[0] == "update")
     assert ups == [(p, q) for p in range(P) for q in range(p + 1, P)]
