@@ -74,7 +74,7 @@ def _worker(rank, world, port, n, d, ns, out_dir, bcast="broadcast"):
 
 @pytest.mark.parametrize("world,n,bcast", [(2, 1300, "broadcast"), (3, 2100, "broadcast"), (2, 1300, "scatter_allgather"),
                                            (4, 2100, "scatter_allgather"), (2, 1300, "auto"), (4, 700, "broadcast"),
-                                           (2, 1300, "whole_panel")])
+                                           (2, 1300, "whole_panel"), (4, 3100, "scatter_allgather"), (3, 3100, "whole_panel")])
 def test_block_cyclic_fit_and_sliced_predict(tmp_path, world, n, bcast):
     """bcast: how a factored panel reaches the other ranks -- one rooted broadcast, or scatter + all-gather (the
     large-message form for point-to-point links); "auto" runs the calibration that picks one.  Same results."""
