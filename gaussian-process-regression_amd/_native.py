@@ -86,6 +86,7 @@ PROTOTYPES = {
     "gprc_dev_factor_subpanel": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _vp]),
     "gprc_dev_factor_all": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "gprc_dev_update_trailing": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64]),
+    "gprc_dev_update_range": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64]),
     "gprc_trsv_work_size": (_i64, [_i64]),
     "gprc_dev_trsv": (C.c_int, [_vp, _vp, _vp, _i64, _vp, C.c_int, _vp]),
     "gprc_dev_fill_cross": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64]),

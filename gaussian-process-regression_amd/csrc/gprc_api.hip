@@ -1073,6 +1073,13 @@ int gprc_dev_factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* wi
   if (!packed || !winv || !info_dev || n_pad <= 0 || n_pad % NB) { set_error("dev_factor_all: bad arguments"); return GPRC_ERR_ARG; }
   return factor_all_async(ctx, packed, n_pad, winv, info_dev);
 }
+int gprc_dev_update_range(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p_begin, int64_t p_end, int64_t q_begin, int64_t q_end,
+                          int64_t q_stride) {
+  GPRC_TRY(use_device(ctx));
+  if (!packed || n_pad <= 0 || n_pad % NB || p_begin < 0 || p_end > n_pad / NB) { set_error("dev_update_range: bad arguments"); return GPRC_ERR_ARG; }
+  if (p_end - p_begin == 1) return launch_trailing_update(ctx->stream, packed, n_pad, p_begin, q_begin, q_end, q_stride);  // the K = 512 kernel
+  return launch_trailing_range(ctx->stream, packed, n_pad, p_begin, p_end, q_begin, q_end, q_stride);
+}
 int gprc_dev_update_trailing(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, int64_t q_begin,
                              int64_t q_end, int64_t q_stride) {
   GPRC_TRY(use_device(ctx));

@@ -346,7 +346,7 @@ __device__ __forceinline__ const double* strip_ktile(const double* B, int64_t ld
 
 template <bool SET, bool SEG = false, bool SEGA = false>
 __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
-                                              int64_t ldb, int K, double* smem, int64_t brow = 0, int64_t arow = 0) {
+                                              int64_t ldb, int K, double* smem, int64_t brow = 0, int64_t arow = 0, int kt0 = 0) {
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -367,8 +367,8 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
       for (int m = 0; m < 4; ++m) acc[m][n][r] = SET ? 0.0 : Cw[m * 16 + (int64_t)(n * 16 + 4 * r) * ldc];
 
   int64_t ldak, ldbk;
-  const double* Ag = strip_ktile<SEGA>(A, lda, arow, 0, lane, wave, ldak);  // this lane's 16 bytes of k-slice `wave`
-  const double* Bg = strip_ktile<SEG>(B, ldb, brow, 0, lane, wave, ldbk);
+  const double* Ag = strip_ktile<SEGA>(A, lda, arow, kt0, lane, wave, ldak);  // this lane's 16 bytes of k-slice `wave`
+  const double* Bg = strip_ktile<SEG>(B, ldb, brow, kt0, lane, wave, ldbk);
   const int srow = wave * G_LDT;                          // LDS row of that slice (wave-uniform)
   const int foff = fr + fk * G_LDT;                       // this lane's MFMA operand element
 
@@ -388,8 +388,8 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   if (KT > 1) {
-    Ag = strip_ktile<SEGA>(A, lda, arow, 1, lane, wave, ldak);
-    Bg = strip_ktile<SEG>(B, ldb, brow, 1, lane, wave, ldbk);
+    Ag = strip_ktile<SEGA>(A, lda, arow, kt0 + 1, lane, wave, ldak);
+    Bg = strip_ktile<SEG>(B, ldb, brow, kt0 + 1, lane, wave, ldbk);
     dma_ktile(Ag, ldak, Bg, ldbk, As + G_BUF + srow, Bs + G_BUF + srow);
   }
   if constexpr (!SEGA) Ag = A + 2 * lane + (int64_t)(2 * G_KB + wave) * lda;  // next tile to request: kt + 2
@@ -418,8 +418,8 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 has landed (this wave's share)
       __syncthreads();                                   // ... everyone's share; and buffer `cur` is drained
       if (kt + 2 < KT) {
-        if constexpr (SEGA) Ag = strip_ktile<true>(A, lda, arow, kt + 2, lane, wave, ldak);
-        if constexpr (SEG) Bg = strip_ktile<true>(B, ldb, brow, kt + 2, lane, wave, ldbk);
+        if constexpr (SEGA) Ag = strip_ktile<true>(A, lda, arow, kt0 + kt + 2, lane, wave, ldak);
+        if constexpr (SEG) Bg = strip_ktile<true>(B, ldb, brow, kt0 + kt + 2, lane, wave, ldbk);
         dma_ktile(Ag, ldak, Bg, ldbk, As + cur + srow, Bs + cur + srow);
         if constexpr (!SEGA) Ag += (int64_t)G_KB * lda;
         if constexpr (!SEG) Bg += (int64_t)G_KB * ldb;
@@ -538,19 +538,21 @@ __global__ __launch_bounds__(256, 2) void solve_left_kernel(double* vt, int64_t 
 }
 
 
-// Left-looking form of the trailing update for a GROUP of target panels [q_begin, q_begin + n_targets): every lower
-// tile of those panels receives the contributions of ALL panels before the group in one pass,
-//   A[R.., C..] -= L[R.., 0 : K] * L[C.., 0 : K]^T,   K = q_begin NB,
-// both operand strips walking through the packed panels.  Same products, same order as the right-looking passes
-// p = 0 .. q_begin - 1 (k ascending from the loaded C value): bit-identical, one C load/store and one tile prologue
-// instead of q_begin.
-__global__ __launch_bounds__(256, 2) void trailing_left_kernel(double* packed, int64_t n_pad, int q_begin, int n_targets, int ntiles) {
+// Trailing update by a RANGE of source panels [p_begin, p_end) in one pass: every lower tile of the target panels
+// q_begin, q_begin + q_stride, ... (n_targets of them) receives
+//   A[R.., C..] -= L[R.., p_begin NB : p_end NB] * L[C.., p_begin NB : p_end NB]^T,
+// both operand strips walking through the packed panels.  Same products, same order as the single-panel passes
+// p = p_begin .. p_end - 1 (k ascending from the loaded C value): bit-identical, one C load/store and one tile prologue
+// instead of p_end - p_begin.  p_begin = 0 is the left-looking sweep of one GPU; the multi-rank driver uses it to apply
+// the panels it has received in batches.
+__global__ __launch_bounds__(256, 2) void trailing_range_kernel(double* packed, int64_t n_pad, int p_begin, int p_end, int q_begin,
+                                                                int q_stride, int n_targets, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int P = (int)(n_pad / NB);
   constexpr int DIAG_TILES = TPP * (TPP + 1) / 2;
   int id = (int)xcd_remap(blockIdx.x, (unsigned)ntiles);
   int q = q_begin, s = 0;
-  for (; s < n_targets; ++s, ++q) {
+  for (; s < n_targets; ++s, q += q_stride) {
     const int tq = TPP * TPP * (P - q) - TPP * (TPP - 1) / 2;
     if (id < tq) break;
     id -= tq;
@@ -568,8 +570,8 @@ __global__ __launch_bounds__(256, 2) void trailing_left_kernel(double* packed, i
   const int64_t ldq = panel_ld(n_pad, q);
   double* Cq = packed + panel_offset(n_pad, q);
   const int64_t row = (int64_t)q * NB + (int64_t)tr * 128, col = (int64_t)q * NB + (int64_t)tc * 128;
-  gemm_tile_128<false, true, true>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, packed, n_pad, packed, n_pad, q_begin * NB, smem,
-                                   col, row);
+  gemm_tile_128<false, true, true>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, packed, n_pad, packed, n_pad,
+                                   (p_end - p_begin) * NB, smem, col, row, p_begin * (NB / 16));
 }
 
 }  // namespace
@@ -607,7 +609,7 @@ static int ensure_gemm_attrs() {
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_left_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_left_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_range_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   if (dev >= 0 && dev < MAX_DEVICES) done[dev] = true;
   return 0;
 }
@@ -682,27 +684,36 @@ int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t
   return 0;
 }
 
-// left-looking update of target panels [q_begin, q_end) with every panel before q_begin
-int launch_trailing_left(hipStream_t s, double* packed, int64_t n_pad, int64_t q_begin, int64_t q_end) {
+// target panels q_begin, q_begin + q_stride, ... < q_end updated with the source panels [p_begin, p_end) in one pass
+int launch_trailing_range(hipStream_t s, double* packed, int64_t n_pad, int64_t p_begin, int64_t p_end, int64_t q_begin, int64_t q_end,
+                          int64_t q_stride) {
   const int64_t P = n_pad / NB;
   if (q_end > P) q_end = P;
-  if (q_begin <= 0 || q_begin >= q_end) return 0;
+  if (p_begin < 0 || p_end <= p_begin || q_stride <= 0) return 0;
+  if (q_begin < p_end) { set_error("trailing_range: a target panel is not behind the source range"); return GPRC_ERR_ARG; }
+  if (q_begin >= q_end) return 0;
   GPRC_TRY(ensure_gemm_attrs());
-  int64_t tiles = 0;
+  int64_t tiles = 0, nt = 0;
   double fl = 0.0, by = 0.0;
-  const double K = (double)q_begin * NB;
-  for (int64_t q = q_begin; q < q_end; ++q) {
+  const double K = (double)(p_end - p_begin) * NB;
+  for (int64_t q = q_begin; q < q_end; q += q_stride) {
     tiles += (int64_t)TPP * TPP * (P - q) - TPP * (TPP - 1) / 2;
+    ++nt;
     const double rows = (double)(n_pad - q * NB);
     const double elems = rows * NB - 0.5 * NB * (double)(NB - 1);
     fl += 2.0 * elems * K;
     by += 8.0 * (2.0 * elems + rows * K);
   }
   ProfScope ps(s, PK_TRAILING_LEFT, fl, by);
-  hipLaunchKernelGGL(trailing_left_kernel, dim3((unsigned)tiles), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)q_begin,
-                     (int)(q_end - q_begin), (int)tiles);
+  hipLaunchKernelGGL(trailing_range_kernel, dim3((unsigned)tiles), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad,
+                     (int)p_begin, (int)p_end, (int)q_begin, (int)q_stride, (int)nt, (int)tiles);
   GPRC_LAUNCH_CHECK();
   return 0;
+}
+
+// left-looking update of target panels [q_begin, q_end) with every panel before q_begin
+int launch_trailing_left(hipStream_t s, double* packed, int64_t n_pad, int64_t q_begin, int64_t q_end) {
+  return launch_trailing_range(s, packed, n_pad, 0, q_begin, q_begin, q_end, 1);
 }
 
 }  // namespace gprc

@@ -261,6 +261,12 @@ class HipOps:
         if q0 < q1:
             nat.check(self.L.gprc_dev_update_trailing(self._ctx(side), packed.data_ptr(), self.geom.n_pad, p, q0, q1, stride))
 
+    def update_range(self, packed, p0, p1, q0, q1, stride, side):
+        """Source panels [p0, p1) applied to the targets q0, q0 + stride, ... < q1 in one pass (bit-identical to p1 - p0
+        single-panel updates in order)."""
+        if q0 < q1 and p0 < p1:
+            nat.check(self.L.gprc_dev_update_range(self._ctx(side), packed.data_ptr(), self.geom.n_pad, p0, p1, q0, q1, stride))
+
     def trsv(self, packed, winv, b, transpose, work):
         nat.check(self.L.gprc_dev_trsv(self._ctx(False), packed.data_ptr(), winv.data_ptr(), self.geom.n_pad, b.data_ptr(), int(transpose),
                                        work.data_ptr()))
@@ -313,6 +319,11 @@ class DistributedGPR:
         # pipelined panel exchange: the owner broadcasts each 128-column quarter of a panel as soon as it is final,
         # while it is still factoring the rest (GPRC_PIPE_BCAST=0: factor the whole panel, then one broadcast)
         self.pipeline = os.environ.get("GPRC_PIPE_BCAST", "1") != "0" and hasattr(ops, "factor_subpanel")
+        # batched trailing update: a rank applies the panels it has received to its FAR panels (everything but the one
+        # it has to factor next) only every `batch` steps, all of them in one pass with the C tiles held in the
+        # accumulators -- the left-looking saving (one tile prologue and one C load/store per batch instead of per
+        # panel); the panel a rank factors next is always brought up to date at once.  GPRC_UPDATE_BATCH=1: per panel.
+        self.batch = max(1, int(os.environ.get("GPRC_UPDATE_BATCH", "4"))) if hasattr(ops, "update_range") else 1
         g = ops.geom
         self.geom = g
         self.packed = ops.zeros(g.packed_size)
@@ -339,26 +350,32 @@ class DistributedGPR:
             return self._finish_fit(y_pad)
         ops.fork_side()
         self._factor_and_share(0)
+        far_from = 0                                          # panels [0, far_from) are applied to all my unfactored panels
         for p in range(P):                                    # F2: right-looking, one panel per step
             ops.join_side()                                   # panel p factored (owner) / received (others)
             if p + 1 < P:
                 nxt = (p + 1) % G
-                if rank == nxt and not self.lookahead:
-                    with ops.on(False):
-                        ops.update_trailing(self.packed, p, p + 1, P, G, False)
+                mine = rank == nxt                            # I factor panel p + 1 next
+                flush = (p + 1 - far_from >= self.batch) or p + 2 >= P
+                if mine and not self.lookahead:
+                    with ops.on(False):                       # no look-ahead: bring all my panels up to date, then factor
+                        ops.update_range(self.packed, far_from, p + 1, p + 1, P, G, False)
+                    far_from = p + 1
                     ops.fork_side()
                     self._factor_and_share(p + 1)
                     continue
-                if rank == nxt:
+                if mine:
                     ops.fork_side()                           # look-ahead: panel p+1 first, on the side stream
                     with ops.on(True):
-                        ops.update_trailing(self.packed, p, p + 1, p + 2, 1, True)
+                        ops.update_range(self.packed, far_from, p + 1, p + 1, p + 2, 1, True)
                     q0 = p + 1 + G
                 else:
                     q0 = owned_after(p, rank, G)
                 self._factor_and_share(p + 1)                 # owner: side stream; everybody: broadcasts on the comm stream
-                with ops.on(False):
-                    ops.update_trailing(self.packed, p, q0, P, G, False)   # runs beside the factorisation and the exchange
+                if flush:
+                    with ops.on(False):                       # runs beside the factorisation and the exchange
+                        ops.update_range(self.packed, far_from, p + 1, q0, P, G, False)
+                    far_from = p + 1
         ops.join_side()
         return self._finish_fit(y_pad)
 

@@ -191,6 +191,11 @@ GPRC_API int gprc_dev_factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, d
 /* trailing update of panels q = q_begin, q_begin + q_stride, ... < q_end with factored panel p */
 GPRC_API int gprc_dev_update_trailing(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, int64_t q_begin,
                              int64_t q_end, int64_t q_stride);
+/* the same for a RANGE of source panels [p_begin, p_end) in one pass (the C tiles stay in the accumulators across the
+ * whole range): bit-identical to p_end - p_begin single-panel updates in order.  Targets q_begin, q_begin + q_stride,
+ * ... < q_end must all lie behind the range (q_begin >= p_end). */
+GPRC_API int gprc_dev_update_range(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p_begin, int64_t p_end, int64_t q_begin,
+                          int64_t q_end, int64_t q_stride);
 /* b := L^-1 b (transpose == 0) or L^-T b (transpose != 0); work: gprc_trsv_work_size(n_pad) doubles */
 GPRC_API int64_t gprc_trsv_work_size(int64_t n_pad);
 GPRC_API int gprc_dev_trsv(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose,

@@ -132,6 +132,10 @@ class OracleOps:
             self._panel(packed, q)[...] -= Lp[r0:, :] @ Lp[r0:r0 + g.NB, :].T
             self.log.append(("update", p, q, bool(side)))
 
+    def update_range(self, packed, p0, p1, q0, q1, stride, side):
+        for p in range(p0, p1):                       # the same products in the same order, panel by panel
+            self.update_trailing(packed, p, q0, q1, stride, side)
+
     def trsv(self, packed, winv, b, transpose, work):
         L = self.dense_L(packed)
         b.numpy()[...] = sl.solve_triangular(L.T if transpose else L, b.numpy(), lower=not transpose)
