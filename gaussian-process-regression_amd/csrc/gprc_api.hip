@@ -1094,6 +1094,12 @@ int gprc_dev_trsv(gprc_ctx* ctx, const double* packed, const double* winv, int64
   return launch_trsv(ctx->stream, packed, winv, n_pad, b, transpose, work);
 }
 
+int gprc_dev_trsv_step(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose, int64_t p) {
+  GPRC_TRY(use_device(ctx));
+  if (!packed || !winv || !b || n_pad <= 0 || n_pad % NB) { set_error("dev_trsv_step: bad arguments"); return GPRC_ERR_ARG; }
+  return launch_trsv_step(ctx->stream, packed, winv, n_pad, b, transpose, (int)p);
+}
+
 int gprc_dev_fill_cross(gprc_ctx* ctx, int kernel, const double* params_host, int n_params, const double* X_star,
                         int64_t d, int64_t m, int64_t m_pad, const double* X, int64_t n, int64_t n_pad, double* vt,
                         int64_t ld) {

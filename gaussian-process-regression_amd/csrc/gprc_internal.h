@@ -94,6 +94,7 @@ int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t
 int launch_trailing_left(hipStream_t s, double* packed, int64_t n_pad, int64_t q_begin, int64_t q_end);
 int launch_trailing_range(hipStream_t s, double* packed, int64_t n_pad, int64_t p_begin, int64_t p_end, int64_t q_begin, int64_t q_end,
                           int64_t q_stride);
+int launch_trsv_step(hipStream_t s, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose, int p);
 int launch_trsv(hipStream_t s, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose, double* work);
 int64_t rowreduce_splits(int64_t cols);
 int launch_row_reduce(hipStream_t s, const double* vt, int64_t ld, int64_t rows, int64_t cols, const double* w, double* out,

@@ -44,41 +44,65 @@ __device__ __forceinline__ double wave_sum(double s) {
 }
 
 // x_p = L_pp^-1 b_p in place.  1024 threads: (i = t & 127) x (ty = t >> 7, eight column groups).
-__global__ __launch_bounds__(1024) void trsv_diag_fwd(const double* packed, const double* winv, int64_t n_pad, int p, double* b) {
-  __shared__ double z[NB];
-  __shared__ double red[8][128];
-  const int t = threadIdx.x, i = t & 127, ty = t >> 7;
-  const int64_t ld = panel_ld(n_pad, p);
-  const double* pan = packed + panel_offset(n_pad, p);
-  double* bp = b + (int64_t)p * NB;
-  if (t < NB) z[t] = bp[t];
-  __syncthreads();
-  for (int j = 0; j < TPP; ++j) {
-    if (j > 0) {  // z_j -= L[j-th row block, columns 0 .. 128j) * x[0 .. 128j)
-      const double* Lr = pan + j * 128 + i;
-      double s = 0.0;
-      for (int c = ty; c < j * 128; c += 8) s = fma(Lr[(int64_t)c * ld], z[c], s);
-      red[ty][i] = s;
-      __syncthreads();
-      if (ty == 0) {
-        double v = z[j * 128 + i];
-        for (int g = 0; g < 8; ++g) v -= red[g][i];
-        z[j * 128 + i] = v;
-      }
-      __syncthreads();
-    }
-    const double* W = winv + ((int64_t)p * TPP + j) * 128 * 128;
+// One workgroup, latency-bound: every phase first issues ALL its global loads (fixed trip counts, fully unrolled --
+// 16 J + 16 of them in flight per thread) and only then runs the FMA chain, in the original summation order.  With the
+// loads issued one per loop iteration the kernel spent ~48 dependent HBM round trips per solve (89 us).
+template <int J>
+__device__ __forceinline__ void trsv_fwd_phase(const double* pan, int64_t ld, const double* W, double* z, double (*red)[128], int i, int ty) {
+  if constexpr (J > 0) {  // z_J -= L[J-th row block, columns 0 .. 128 J) * x[0 .. 128 J)
+    const double* Lr = pan + J * 128 + i;
+    double lv[16 * J];
+#pragma unroll
+    for (int k = 0; k < 16 * J; ++k) lv[k] = Lr[(int64_t)(ty + 8 * k) * ld];
     double s = 0.0;
-    for (int c = ty; c <= i; c += 8) s = fma(W[i + c * 128], z[j * 128 + c], s);
+#pragma unroll
+    for (int k = 0; k < 16 * J; ++k) s = fma(lv[k], z[ty + 8 * k], s);
     red[ty][i] = s;
     __syncthreads();
     if (ty == 0) {
-      double v = 0.0;
-      for (int g = 0; g < 8; ++g) v += red[g][i];
-      z[j * 128 + i] = v;
+      double v = z[J * 128 + i];
+      for (int g = 0; g < 8; ++g) v -= red[g][i];
+      z[J * 128 + i] = v;
     }
     __syncthreads();
   }
+  double wv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int c = ty + 8 * k;
+    wv[k] = (c <= i) ? W[i + c * 128] : 0.0;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int c = ty + 8 * k;
+    if (c <= i) s = fma(wv[k], z[J * 128 + c], s);
+  }
+  red[ty][i] = s;
+  __syncthreads();
+  if (ty == 0) {
+    double v = 0.0;
+    for (int g = 0; g < 8; ++g) v += red[g][i];
+    z[J * 128 + i] = v;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void trsv_diag_fwd(const double* packed, const double* winv, int64_t n_pad, int p, double* b) {
+  __shared__ double z[NB];
+  __shared__ double red[8][128];
+  static_assert(TPP == 4, "trsv_diag_fwd is written for four 128-blocks per panel");
+  const int t = threadIdx.x, i = t & 127, ty = t >> 7;
+  const int64_t ld = panel_ld(n_pad, p);
+  const double* pan = packed + panel_offset(n_pad, p);
+  const double* W = winv + (int64_t)p * TPP * 128 * 128;
+  double* bp = b + (int64_t)p * NB;
+  if (t < NB) z[t] = bp[t];
+  __syncthreads();
+  trsv_fwd_phase<0>(pan, ld, W, z, red, i, ty);
+  trsv_fwd_phase<1>(pan, ld, W + 128 * 128, z, red, i, ty);
+  trsv_fwd_phase<2>(pan, ld, W + 2 * 128 * 128, z, red, i, ty);
+  trsv_fwd_phase<3>(pan, ld, W + 3 * 128 * 128, z, red, i, ty);
   if (t < NB) bp[t] = z[t];
 }
 
@@ -107,37 +131,66 @@ __global__ __launch_bounds__(512) void trsv_gemv_below(const double* packed, int
 }
 
 // x_p = L_pp^-T z_p in place.  16 waves; a wave owns columns w, w+16, ... and reduces over rows with its lanes.
+// One backward phase: block J of the panel's diagonal (16 waves; wave w handles columns w, w + 16, ...; lanes stride the
+// rows).  All loads of the eight columns a wave owns are issued before the first reduction.
+template <int J>
+__device__ __forceinline__ void trsv_bwd_phase(const double* pan, int64_t ld, const double* W, double* z, double* v, int lane, int w) {
+  constexpr int NR = (TPP - 1 - J) * 2;  // rows below block J inside the panel, 64 per step
+  {  // v[c] = z_J[c] - sum_{r >= 128 (J+1)} L[r, 128 J + c] * x[r]
+    double lv[8][NR > 0 ? NR : 1];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double* col = pan + (int64_t)(J * 128 + w + 16 * k) * ld;
+#pragma unroll
+      for (int q = 0; q < NR; ++q) lv[k][q] = col[(J + 1) * 128 + lane + 64 * q];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < NR; ++q) s = fma(lv[k][q], z[(J + 1) * 128 + lane + 64 * q], s);
+      s = wave_sum(s);
+      if (lane == 0) v[w + 16 * k] = z[J * 128 + w + 16 * k] - s;
+    }
+  }
+  __syncthreads();
+  {  // x_J[c'] = sum_{c >= c'} W_J[c, c'] * v[c]
+    double wv[8][2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int cp = w + 16 * k;
+      const double* wc = W + cp * 128;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) wv[k][q] = (lane + 64 * q >= cp) ? wc[lane + 64 * q] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int cp = w + 16 * k;
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (lane + 64 * q >= cp) s = fma(wv[k][q], v[lane + 64 * q], s);
+      s = wave_sum(s);
+      if (lane == 0) z[J * 128 + cp] = s;
+    }
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(1024) void trsv_diag_bwd(const double* packed, const double* winv, int64_t n_pad, int p, double* x) {
   __shared__ double z[NB];
   __shared__ double v[128];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int64_t ld = panel_ld(n_pad, p);
   const double* pan = packed + panel_offset(n_pad, p);
+  const double* W = winv + (int64_t)p * TPP * 128 * 128;
   double* xp = x + (int64_t)p * NB;
   if (t < NB) z[t] = xp[t];
   __syncthreads();
-  for (int j = TPP - 1; j >= 0; --j) {
-    // v[c] = z_j[c] - sum_{r >= 128(j+1)} L[r, 128j + c] * x[r]
-    for (int c = w; c < 128; c += 16) {
-      const double* col = pan + (int64_t)(j * 128 + c) * ld;
-      double s = 0.0;
-      for (int r = (j + 1) * 128 + lane; r < NB; r += 64) s = fma(col[r], z[r], s);
-      s = wave_sum(s);
-      if (lane == 0) v[c] = z[j * 128 + c] - s;
-    }
-    __syncthreads();
-    // x_j[c'] = sum_{c >= c'} W_j[c, c'] * v[c]
-    const double* W = winv + ((int64_t)p * TPP + j) * 128 * 128;
-    for (int cp = w; cp < 128; cp += 16) {
-      const double* wc = W + cp * 128;
-      double s = 0.0;
-      for (int c = lane; c < 128; c += 64)
-        if (c >= cp) s = fma(wc[c], v[c], s);
-      s = wave_sum(s);
-      if (lane == 0) z[j * 128 + cp] = s;
-    }
-    __syncthreads();
-  }
+  trsv_bwd_phase<3>(pan, ld, W + 3 * 128 * 128, z, v, lane, w);
+  trsv_bwd_phase<2>(pan, ld, W + 2 * 128 * 128, z, v, lane, w);
+  trsv_bwd_phase<1>(pan, ld, W + 128 * 128, z, v, lane, w);
+  trsv_bwd_phase<0>(pan, ld, W, z, v, lane, w);
   if (t < NB) xp[t] = z[t];
 }
 
@@ -356,23 +409,30 @@ inline unsigned blocks(int64_t n, int per) { return (unsigned)((n + per - 1) / p
 
 int64_t rowreduce_splits(int64_t cols) { return (cols + RR_COLS - 1) / RR_COLS; }
 
+// one panel step of the solve: the diagonal block of panel p, then its contribution to the rest of the right-hand side
+int launch_trsv_step(hipStream_t s, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose, int p) {
+  const int P = (int)(n_pad / NB);
+  if (p < 0 || p >= P) { set_error("trsv_step: panel out of range"); return GPRC_ERR_ARG; }
+  if (!transpose) {
+    hipLaunchKernelGGL(trsv_diag_fwd, dim3(1), dim3(1024), 0, s, packed, winv, n_pad, p, b);
+    const int64_t below = n_pad - (int64_t)(p + 1) * NB;
+    if (below > 0) hipLaunchKernelGGL(trsv_gemv_below, dim3((unsigned)(below / 128)), dim3(512), 0, s, packed, n_pad, p, b);
+  } else {
+    hipLaunchKernelGGL(trsv_diag_bwd, dim3(1), dim3(1024), 0, s, packed, winv, n_pad, p, b);
+    if (p > 0) hipLaunchKernelGGL(trsv_gemvt_above, dim3((unsigned)(p * (NB / 32))), dim3(256), 0, s, packed, n_pad, p, b);
+  }
+  GPRC_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_trsv(hipStream_t s, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose, double* work) {
   (void)work;
   const int P = (int)(n_pad / NB);
   ProfScope ps(s, PK_TRSV, (double)n_pad * n_pad, 8.0 * 0.5 * n_pad * n_pad);
-  if (!transpose) {
-    for (int p = 0; p < P; ++p) {
-      hipLaunchKernelGGL(trsv_diag_fwd, dim3(1), dim3(1024), 0, s, packed, winv, n_pad, p, b);
-      const int64_t below = n_pad - (int64_t)(p + 1) * NB;
-      if (below > 0) hipLaunchKernelGGL(trsv_gemv_below, dim3((unsigned)(below / 128)), dim3(512), 0, s, packed, n_pad, p, b);
-    }
-  } else {
-    for (int p = P - 1; p >= 0; --p) {
-      hipLaunchKernelGGL(trsv_diag_bwd, dim3(1), dim3(1024), 0, s, packed, winv, n_pad, p, b);
-      if (p > 0) hipLaunchKernelGGL(trsv_gemvt_above, dim3((unsigned)(p * (NB / 32))), dim3(256), 0, s, packed, n_pad, p, b);
-    }
-  }
-  GPRC_LAUNCH_CHECK();
+  if (!transpose)
+    for (int p = 0; p < P; ++p) GPRC_TRY(launch_trsv_step(s, packed, winv, n_pad, b, 0, p));
+  else
+    for (int p = P - 1; p >= 0; --p) GPRC_TRY(launch_trsv_step(s, packed, winv, n_pad, b, 1, p));
   return 0;
 }
 

@@ -188,8 +188,11 @@ class HipOps:
         prio = int(os.environ.get("GPRC_SIDE_PRIORITY", "-1"))
         self.side_stream = torch.cuda.Stream(device=self.device, priority=prio)
         self.comm_stream = torch.cuda.Stream(device=self.device, priority=prio)   # where the panel broadcasts are posted
+        self.aux_stream = torch.cuda.Stream(device=self.device)                   # the forward solve, run beside the sweep
+        self.ctx_aux = None
         self.ctx_main = nat.Context(device, self.main_stream.cuda_stream)
         self.ctx_side = nat.Context(device, self.side_stream.cuda_stream)
+        self.ctx_aux = nat.Context(device, self.aux_stream.cuda_stream)
         self.kernel_id = int(kernel_id)
         self.params, self._pp, self._np = nat.params_array(params)
         self.d, self.n, self.noise = int(d), int(n), float(noise)
@@ -231,10 +234,22 @@ class HipOps:
         self.main_stream.wait_stream(self.side_stream)
         self.main_stream.wait_stream(self.comm_stream)
 
+    def aux_after_panel(self):
+        """The auxiliary stream waits for the panel just completed (factored on the side stream / received on comm)."""
+        self.aux_stream.wait_stream(self.side_stream)
+        self.aux_stream.wait_stream(self.comm_stream)
+
+    def aux_after_main(self):
+        self.aux_stream.wait_stream(self.main_stream)
+
+    def join_aux(self):
+        self.main_stream.wait_stream(self.aux_stream)
+
     def synchronize(self):
         self.main_stream.synchronize()
         self.side_stream.synchronize()
         self.comm_stream.synchronize()
+        self.aux_stream.synchronize()
 
     def _ctx(self, side):
         return (self.ctx_side if side else self.ctx_main).handle
@@ -271,6 +286,11 @@ class HipOps:
         nat.check(self.L.gprc_dev_trsv(self._ctx(False), packed.data_ptr(), winv.data_ptr(), self.geom.n_pad, b.data_ptr(), int(transpose),
                                        work.data_ptr()))
 
+    def trsv_step_aux(self, packed, winv, b, p):
+        """Forward-solve step of panel p on the auxiliary stream."""
+        with self.torch.cuda.stream(self.aux_stream):
+            nat.check(self.L.gprc_dev_trsv_step(self.ctx_aux.handle, packed.data_ptr(), winv.data_ptr(), self.geom.n_pad, b.data_ptr(), 0, p))
+
     def logp(self, packed, y, alpha, out):
         nat.check(self.L.gprc_dev_logp(self._ctx(False), packed.data_ptr(), self.geom.n_pad, self.n, y.data_ptr(), alpha.data_ptr(),
                                        out.data_ptr()))
@@ -296,6 +316,7 @@ class HipOps:
         self.synchronize()
         self.ctx_main.close()
         self.ctx_side.close()
+        self.ctx_aux.close()
 
 
 def owned_after(p: int, rank: int, world: int) -> int:
@@ -348,10 +369,20 @@ class DistributedGPR:
             with ops.on(False):                               # one rank, nothing to exchange: the whole sweep natively
                 ops.factor_all(self.packed, self.winv, self.info)
             return self._finish_fit(y_pad)
+        # F3 starts inside F2: the forward solve L z = y needs only panels <= p at step p, so it runs on an auxiliary
+        # stream beside the trailing updates (128 latency-bound steps that would otherwise follow the sweep)
+        self._fwd_in_sweep = hasattr(ops, "trsv_step_aux")
+        if self._fwd_in_sweep:
+            with ops.on(False):
+                _copy(self.alpha, y_pad)
+            ops.aux_after_main()
         ops.fork_side()
         self._factor_and_share(0)
         far_from = 0                                          # panels [0, far_from) are applied to all my unfactored panels
         for p in range(P):                                    # F2: right-looking, one panel per step
+            if self._fwd_in_sweep:
+                ops.aux_after_panel()                         # panel p and its inverses are complete on side / comm
+                ops.trsv_step_aux(self.packed, self.winv, self.alpha, p)
             ops.join_side()                                   # panel p factored (owner) / received (others)
             if p + 1 < P:
                 nxt = (p + 1) % G
@@ -377,7 +408,9 @@ class DistributedGPR:
                         ops.update_range(self.packed, far_from, p + 1, q0, P, G, False)
                     far_from = p + 1
         ops.join_side()
-        return self._finish_fit(y_pad)
+        if self._fwd_in_sweep:
+            ops.join_aux()
+        return self._finish_fit(y_pad, forward_done=self._fwd_in_sweep)
 
     def _factor_and_share(self, p):
         """Panel p has received every update on its owner: factor it there (side stream) and replicate it (comm stream).
@@ -404,14 +437,15 @@ class DistributedGPR:
         with ops.on_comm():
             comm.broadcast(self.winv[g.winv_slice(p)], src)   # the four inverses were complete before the last quarter left
 
-    def _finish_fit(self, y_pad):
+    def _finish_fit(self, y_pad, forward_done=False):
         ops, comm = self.ops, self.comm
         self.info_value = comm.min_positive(ops.read_info(self.info))
         if self.info_value != 0:
             return self.info_value
         with ops.on(False):                                   # F3: replicated, L is complete everywhere
-            _copy(self.alpha, y_pad)
-            ops.trsv(self.packed, self.winv, self.alpha, False, self.work)
+            if not forward_done:
+                _copy(self.alpha, y_pad)
+                ops.trsv(self.packed, self.winv, self.alpha, False, self.work)
             ops.trsv(self.packed, self.winv, self.alpha, True, self.work)
             ops.logp(self.packed, y_pad, self.alpha, self.scal)
         return 0

@@ -200,6 +200,10 @@ GPRC_API int gprc_dev_update_range(gprc_ctx* ctx, double* packed, int64_t n_pad,
 GPRC_API int64_t gprc_trsv_work_size(int64_t n_pad);
 GPRC_API int gprc_dev_trsv(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose,
                   double* work);
+/* one panel step of that solve (forward: p = 0, 1, ...; transposed: p = P-1, ..., 0): the forward solve needs only
+ * panels <= p, so a sweep that produces the panels in order can run it beside the factorisation */
+GPRC_API int gprc_dev_trsv_step(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose,
+                       int64_t p);
 /* vt (m_pad x n_pad, leading dimension ld >= m_pad, ld even, m_pad % 128 == 0) = K(X_star, X), zero in the
  * padding.  Keep ld off powers of two (e.g. m_pad + 128): a 2^k-byte column stride aliases HBM channels. */
 GPRC_API int gprc_dev_fill_cross(gprc_ctx* ctx, int kernel, const double* params_host, int n_params, const double* X_star,

@@ -136,6 +136,25 @@ class OracleOps:
         for p in range(p0, p1):                       # the same products in the same order, panel by panel
             self.update_trailing(packed, p, q0, q1, stride, side)
 
+    def aux_after_panel(self):
+        self.log.append(("aux_after_panel",))
+
+    def aux_after_main(self):
+        pass
+
+    def join_aux(self):
+        self.log.append(("join_aux",))
+
+    def trsv_step_aux(self, packed, winv, b, p):
+        """Forward-substitution step of panel p: z_p = L_pp^-1 z_p, then z_below -= L[below, p] z_p."""
+        g = self.geom
+        pan = self._panel(packed, p)
+        z = b.numpy()
+        c0 = p * g.NB
+        z[c0:c0 + g.NB] = sl.solve_triangular(np.tril(pan[:g.NB, :g.NB]), z[c0:c0 + g.NB], lower=True)
+        z[c0 + g.NB:] -= pan[g.NB:, :] @ z[c0:c0 + g.NB]
+        self.log.append(("fwd", p))
+
     def trsv(self, packed, winv, b, transpose, work):
         L = self.dense_L(packed)
         b.numpy()[...] = sl.solve_triangular(L.T if transpose else L, b.numpy(), lower=not transpose)

@@ -97,6 +97,7 @@ def test_block_cyclic_fit_and_sliced_predict(tmp_path, world, n, bcast):
         fills = [e[1] for e in log if e[0] == "fill"]
         assert fills == list(range(r, P, world))              # F1: own panels only
         assert all(e[1] % world == r for e in log if e[0] == "factor")
+        assert [e[1] for e in log if e[0] == "fwd"] == list(range(P))   # the forward solve rides along, one step per panel
         assert all(e[2] % world == r for e in log if e[0] == "update")
         # look-ahead: when this rank owns panel p+1, its update by panel p and its factorisation come before
         # the rest of trailing update p
