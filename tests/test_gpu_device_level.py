@@ -1,0 +1,104 @@
+"""Device-level entry points of the C ABI (gprc_dev_*), called directly on torch-owned device buffers: the alternative
+schedules they offer are bit-identical to the basic one -- factor_panel in quarters, trailing updates by a range of
+panels, the whole-sweep call, the solve in panel steps."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import gprc_amd  # noqa: E402,F401
+from gprc_amd import _native as nat  # noqa: E402
+from gprc_amd.distributed import Geometry  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _filled(n, d=3, seed=31):
+    L = nat.lib()
+    rng = np.random.default_rng(seed)
+    X = torch.from_numpy(np.ascontiguousarray(rng.uniform(-1, 1, (n, d)))).cuda()
+    g = Geometry(n)
+    ctx = nat.Context(0, torch.cuda.current_stream().cuda_stream)
+    par, pp, npar = nat.params_array([0.6])
+    packed = torch.zeros(g.packed_size, dtype=torch.float64, device="cuda")
+    for p in range(g.P):
+        nat.check(L.gprc_dev_fill_panel(ctx.handle, 3, pp, npar, X.data_ptr(), d, n, g.n_pad, 0.1, packed.data_ptr(), p))
+    torch.cuda.synchronize()
+    return L, ctx, g, packed
+
+
+def _new(g):
+    return (torch.zeros(g.winv_size, dtype=torch.float64, device="cuda"), torch.zeros(4, dtype=torch.int32, device="cuda"))
+
+
+def test_sweep_variants_are_bit_identical():
+    n = 2900                                             # 6 panels
+    L, ctx, g, K = _filled(n)
+    P = g.P
+
+    def basic():                                         # factor_panel + one update per panel
+        a = K.clone(); w, info = _new(g)
+        for p in range(P):
+            nat.check(L.gprc_dev_factor_panel(ctx.handle, a.data_ptr(), g.n_pad, p, w.data_ptr(), info.data_ptr()))
+            if p + 1 < P:
+                nat.check(L.gprc_dev_update_trailing(ctx.handle, a.data_ptr(), g.n_pad, p, p + 1, P, 1))
+        torch.cuda.synchronize()
+        return a, w, int(info[0])
+
+    def quarters_and_ranges(batch):                      # factor in 4 x (part 1, part 2); far panels updated in batches
+        a = K.clone(); w, info = _new(g)
+        far_from = 0
+        for p in range(P):
+            if p > 0:                                    # bring panel p up to date, whatever has not been applied yet
+                nat.check(L.gprc_dev_update_range(ctx.handle, a.data_ptr(), g.n_pad, far_from, p, p, p + 1, 1))
+            for j in range(4):
+                for part in (1, 2):
+                    nat.check(L.gprc_dev_factor_subpanel(ctx.handle, a.data_ptr(), g.n_pad, p, j, part, w.data_ptr(), info.data_ptr()))
+            if p + 1 - far_from >= batch or p + 2 >= P:
+                nat.check(L.gprc_dev_update_range(ctx.handle, a.data_ptr(), g.n_pad, far_from, p + 1, p + 1, P, 1))
+                far_from = p + 1
+        torch.cuda.synchronize()
+        return a, w, int(info[0])
+
+    def whole():
+        a = K.clone(); w, info = _new(g)
+        nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr()))
+        torch.cuda.synchronize()
+        return a, w, int(info[0])
+
+    ref = basic()
+    assert ref[2] == 0
+    for name, got in (("batch 1", quarters_and_ranges(1)), ("batch 3", quarters_and_ranges(3)), ("factor_all", whole())):
+        assert got[2] == 0 and torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), name
+    with pytest.raises(nat.GprcError, match="behind the source range"):
+        nat.check(L.gprc_dev_update_range(ctx.handle, K.clone().data_ptr(), g.n_pad, 0, 3, 2, P, 1))
+    ctx.close()
+
+
+def test_solve_in_panel_steps_is_bit_identical():
+    n = 2100
+    L, ctx, g, a = _filled(n, seed=32)
+    w, info = _new(g)
+    nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr()))
+    rng = np.random.default_rng(1)
+    b0 = torch.from_numpy(np.concatenate([rng.normal(size=n), np.zeros(g.n_pad - n)])).cuda()
+    work = torch.zeros(g.trsv_work, dtype=torch.float64, device="cuda")
+    for transpose in (0, 1):
+        whole, steps = b0.clone(), b0.clone()
+        nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, whole.data_ptr(), transpose, work.data_ptr()))
+        order = range(g.P) if not transpose else range(g.P - 1, -1, -1)
+        for p in order:
+            nat.check(L.gprc_dev_trsv_step(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, steps.data_ptr(), transpose, p))
+        torch.cuda.synchronize()
+        assert torch.equal(whole, steps)
+    # and it is a solve: L (L^T x) = b
+    x = b0.clone()
+    nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, x.data_ptr(), 0, work.data_ptr()))
+    nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, x.data_ptr(), 1, work.data_ptr()))
+    torch.cuda.synchronize()
+    from oracle import oracle as orc
+    Xh = np.random.default_rng(32).uniform(-1, 1, (n, 3))
+    Kh = orc.kernel_matrix(orc.SQREXP, [0.6], Xh.T, Xh.T) + 0.1 * np.eye(n)
+    assert np.max(np.abs(Kh @ x.cpu().numpy()[:n] - b0.cpu().numpy()[:n])) <= 1e-10 * np.abs(b0.cpu().numpy()).max() * n
+    ctx.close()
