@@ -257,22 +257,24 @@ int use_device(const gprc_ctx* ctx) {
 // ---- factorisation of all panels of a packed matrix (single GPU) ------------------------------
 // 128-column sub-step j of panel p: factor + invert the diagonal block, solve the rows below it, update the rest of the
 // panel.  After it, columns [128 j, 128 (j+1)) of the panel are final (what the pipelined broadcast relies on).
-// part: 1 = factor + solve (the columns become final), 2 = update of the rest of the panel, 0 = both.
+// 128-column sub-step j of panel p, left-looking inside the panel: first the columns of block j receive the
+// contributions of the blocks 0..j-1 of the same panel in one pass (K = 128 j, C tile in the accumulators: the same
+// products in the same order as three K = 128 updates from the left, with half the C traffic and a third of the
+// launches), then the diagonal block is factored + inverted and the rows below it are solved.  After it the columns
+// [128 j, 128 (j+1)) of the panel are final (what the pipelined broadcast relies on).
+// part: 1 = the whole sub-step, 2 = nothing (kept so that callers written for the right-looking form still work), 0 = 1.
 int factor_subpanel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, int j, int part, double* winv, int* info_dev) {
+  if (part == 2) return 0;
   hipStream_t s = ctx->stream;
   const int64_t ld = panel_ld(n_pad, p);
   double* pan = packed + panel_offset(n_pad, p);
   const int64_t cj = (int64_t)j * NBI;
   double* wblk = winv + (p * (NB / NBI) + j) * NBI * NBI;
+  if (cj > 0)  // rows cj.. of block j's columns -= (rows cj.. of the earlier columns) * (rows cj..cj+127 of the earlier columns)^T
+    GPRC_TRY(launch_gemm_nt(s, pan + cj + cj * ld, ld, pan + cj, ld, pan + cj, ld, ld - cj, NBI, cj, 1, PK_GEMM_INNER));
+  GPRC_TRY(launch_potf2_inv(s, pan + cj + cj * ld, ld, wblk, info_dev, (int)(p * NB + cj)));
   const int64_t below = ld - cj - NBI;
-  double* Lcol = pan + (cj + NBI) + cj * ld;
-  if (part != 2) {
-    GPRC_TRY(launch_potf2_inv(s, pan + cj + cj * ld, ld, wblk, info_dev, (int)(p * NB + cj)));
-    if (below > 0) GPRC_TRY(launch_trsm_panel(s, Lcol, ld, below, wblk));
-  }
-  const int64_t rest = NB - cj - NBI;  // remaining columns of this panel
-  if (part != 1 && below > 0 && rest > 0)
-    GPRC_TRY(launch_gemm_nt(s, pan + (cj + NBI) + (cj + NBI) * ld, ld, Lcol, ld, Lcol, ld, below, rest, NBI, 1, PK_GEMM_INNER));
+  if (below > 0) GPRC_TRY(launch_trsm_panel(s, pan + (cj + NBI) + cj * ld, ld, below, wblk));
   return 0;
 }
 
@@ -339,14 +341,13 @@ int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t 
     for (int64_t p = g0; p < g1; ++p) {
       const int64_t ld = panel_ld(n_pad, p);
       const double* pan = packed + panel_offset(n_pad, p);
-      for (int j = 0; j < NB / NBI; ++j) {
+      for (int j = 0; j < NB / NBI; ++j) {  // inside the panel, left-looking by 128-column blocks (K = 128 j, as factor_subpanel)
         const int64_t cj = p * NB + (int64_t)j * NBI;  // global column
         const double* wblk = winv + (p * (NB / NBI) + j) * NBI * NBI;
+        if (j > 0)
+          GPRC_TRY(launch_gemm_nt(s, vt + cj * ldv, ldv, vt + p * NB * ldv, ldv, pan + (int64_t)j * NBI, ld, m_pad, NBI, (int64_t)j * NBI, 0,
+                                  PK_GEMM_INNER));
         GPRC_TRY(launch_trsm_panel(s, vt + cj * ldv, ldv, m_pad, wblk));
-        const int64_t rest = NB - (j + 1) * NBI;
-        if (rest > 0)
-          GPRC_TRY(launch_gemm_nt(s, vt + (cj + NBI) * ldv, ldv, vt + cj * ldv, ldv, pan + (j + 1) * NBI + (int64_t)j * NBI * ld, ld,
-                                  m_pad, rest, NBI, 0, PK_GEMM_INNER));
       }
       const int64_t right = (g1 - (p + 1)) * NB;  // the rest of the group
       if (right > 0)

@@ -431,7 +431,8 @@ class DistributedGPR:
                     ops.factor_subpanel(self.packed, p, j, 1, self.winv, self.info, True)   # factor + solve: columns final
                 ops.comm_after_side()
                 with ops.on(True):
-                    ops.factor_subpanel(self.packed, p, j, 2, self.winv, self.info, True)   # update the rest of the panel
+                    ops.factor_subpanel(self.packed, p, j, 2, self.winv, self.info, True)   # right-looking ops: update the rest of
+                    # the panel (the native ops work left-looking inside the panel: part 1 did everything, part 2 is empty)
             with ops.on_comm():
                 comm.broadcast(self.packed[g.panel_part_slice(p, j)], src)
         with ops.on_comm():

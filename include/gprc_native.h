@@ -179,9 +179,11 @@ GPRC_API int gprc_dev_fill_panel(gprc_ctx* ctx, int kernel, const double* params
 /* factor panel p in place (diagonal blocks in LDS, panel solves, in-panel updates); info_dev is a
  * device int the first non-PD column (1-based) is written to (must be zeroed by the caller) */
 GPRC_API int gprc_dev_factor_panel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev);
-/* the same in steps, j = 0..3 (128 columns each, in order).  part 1: factor + invert the diagonal block and solve the rows
- * below it -- after it the columns [128 j, 128 (j+1)) of the panel, a contiguous range of the packed buffer, are final,
- * so a multi-rank driver can start broadcasting them; part 2: update the rest of the panel with them; part 0: both. */
+/* the same in steps, j = 0..3 (128 columns each, in order).  part 1 (or 0): block j's columns receive the contributions of
+ * the blocks 0..j-1 of the panel (one K = 128 j pass), the diagonal block is factored + inverted and the rows below it
+ * are solved -- after it the columns [128 j, 128 (j+1)) of the panel, a contiguous range of the packed buffer, are
+ * final, so a multi-rank driver can start broadcasting them.  part 2: nothing (accepted so that drivers written for a
+ * right-looking "factor, then update the rest of the panel" split keep working). */
 GPRC_API int gprc_dev_factor_subpanel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, int j, int part, double* winv,
                              int* info_dev);
 /* All panels of an already filled packed matrix on ONE GPU, asynchronously on the context's stream (the one-rank form of
