@@ -70,7 +70,7 @@ struct gprc_ctx {
   bool own_stream = false;
   int* info_dev = nullptr;     // LAPACK info written by the diagonal-block kernel
   double* scal_dev = nullptr;  // 8 doubles of scalar results
-  size_t chunk_bytes = (size_t)16 << 30;  // budget for one K_star^T chunk
+  size_t chunk_bytes = (size_t)40 << 30;  // budget for one K_star^T chunk (n* = n = 65536 in one piece: fewer, fuller launches)
   // grow-only workspace slots (predict chunks): a multi-GiB hipMalloc/hipFree per call costs 100s of ms
   double* ws[4] = {nullptr, nullptr, nullptr, nullptr};
   int64_t ws_cap[4] = {0, 0, 0, 0};
