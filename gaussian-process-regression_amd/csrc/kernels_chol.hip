@@ -118,13 +118,14 @@ __global__ __launch_bounds__(TY * 128) void potf2_inv_kernel(double* A, int64_t 
 //      reciprocal from a Newton-refined v_rsq_f64 -- ~60 dependent cycles instead of the ~600 of the library
 //      sqrt + division);
 //   B  panel rows below: X_I = A_I * Wd^T, and row s of the inverse: X_sJ = Wd * Y_sJ   (4 MFMAs per 16x16 block);
-//   C  Cholesky trailing blocks C_IJ -= X_I X_J^T and inverse blocks Y_IJ -= L_Is X_sJ  (4 MFMAs per block),
-// one barrier after each phase.  L is kept in the lower triangle, the (unscaled-free) inverse transposed in the
+//   C  Cholesky trailing blocks C_IJ -= X_I X_J^T and inverse blocks Y_IJ -= L_Is X_sJ  (4 MFMAs per block); wave 0
+//      updates the next diagonal block first and runs phase A of step s+1 beside the other waves' blocks,
+// one barrier after B and one after C.  L is kept in the lower triangle, the (unscaled-free) inverse transposed in the
 // upper triangle, its diagonal in a side array -- the layout of the output.  The sequential depth drops from 128
 // whole-workgroup steps to 128 single-wave steps on 16-row data.
 // ------------------------------------------------------------------------------------------------
 constexpr int BLD = 144;
-constexpr int PB_SMEM_DOUBLES = PB * BLD + 256 + PB;  // S, Wd, Wdiag
+constexpr int PB_SMEM_DOUBLES = PB * BLD + 512 + PB;  // S, 2 x Wd, Wdiag
 
 // sqrt(d) and 1/sqrt(d) from v_rsq_f64 + two Newton steps (+ one correction of the root)
 __device__ __forceinline__ void sqrt_rsqrt(double d, double& root, double& rinv) {
@@ -207,11 +208,44 @@ __device__ __forceinline__ double4_t block_mma(const double* pa, int lda_, const
   return acc;
 }
 
+// one 16x16 block of phase C: b < nchol -> Cholesky trailing block, else inverse block (see the kernel)
+__device__ __forceinline__ void potf2_phase_c_block(double* S, const double* Wd, int s, int c0, int m, int b, int lane, int q, int r) {
+  const int nchol = m * (m + 1) / 2;
+  if (b < nchol) {
+    int ii = 0;
+    while ((ii + 1) * (ii + 2) / 2 <= b) ++ii;
+    const int I = s + 1 + ii, J = s + 1 + (b - ii * (ii + 1) / 2);
+    // D'[x][y] = C_IJ[y][x]: lanes run down the rows of C_IJ (contiguous in LDS)
+    double4_t acc;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) acc[rr] = S[(16 * I + r) + (16 * J + q + 4 * rr) * BLD];
+    acc = block_mma<1>(S + 16 * J + c0 * BLD, BLD, S + 16 * I + c0 * BLD, BLD, acc);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) S[(16 * I + r) + (16 * J + q + 4 * rr) * BLD] = acc[rr];
+  } else {
+    const int e = b - nchol;
+    const int I = s + 1 + e / (s + 1), J = e % (s + 1);
+    // Y_IJ[a][b'] -= sum_k L_Is[a][k] * X_sJ[k][b'];  Y_IJ[a][b'] sits transposed at S[(16J + b') + (16I + a) * BLD]
+    double4_t acc;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) acc[rr] = S[(16 * J + r) + (16 * I + q + 4 * rr) * BLD];
+    if (J < s) acc = block_mma<1>(S + 16 * I + c0 * BLD, BLD, S + 16 * J + c0 * BLD, BLD, acc);
+    else {  // X_ss = Wd: Bop[k][b'] = Wd[k][b'] = Wd[k + b' * 16]  -> "row index contiguous" means pb[b' + k * ld] with the transposed view
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(16 * I + (lane & 15)) + (c0 + 4 * kk + (lane >> 4)) * BLD],
+                                                   Wd[(4 * kk + (lane >> 4)) + (lane & 15) * 16], acc, 0, 0, 1);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) S[(16 * J + r) + (16 * I + q + 4 * rr) * BLD] = acc[rr];
+  }
+}
+
 __global__ __launch_bounds__(1024) void potf2_inv_blocked_kernel(double* A, int64_t lda, double* winv, int* info, int col0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* S = sm;                      // PB x BLD
-  double* Wd = sm + PB * BLD;          // 16 x 16
-  double* Wdiag = Wd + 256;            // PB
+  double* Wd2 = sm + PB * BLD;         // 2 x (16 x 16): the 16x16 inverse of step s lives in buffer s & 1
+  double* Wdiag = Wd2 + 512;           // PB
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int q = lane >> 4, r = lane & 15;
@@ -220,10 +254,11 @@ __global__ __launch_bounds__(1024) void potf2_inv_blocked_kernel(double* A, int6
     for (int c = ty; c < PB; c += 8) S[i + c * BLD] = (i >= c) ? A[i + (int64_t)c * lda] : 0.0;
   }
   __syncthreads();
+  if (wave == 0) diag16(S, Wd2, Wdiag, info, col0);  // phase A of step 0
+  __syncthreads();
   for (int s = 0; s < 8; ++s) {
     const int c0 = 16 * s, m = 7 - s;
-    if (wave == 0) diag16(S + c0 + c0 * BLD, Wd, Wdiag + c0, info, col0 + c0);
-    __syncthreads();
+    const double* Wd = Wd2 + (s & 1) * 256;
     // ---- phase B: panel below (waves 0..m-1), inverse row s (waves 8..8+s-1)
     if (wave < m) {
       const int I = s + 1 + wave;
@@ -239,38 +274,18 @@ __global__ __launch_bounds__(1024) void potf2_inv_blocked_kernel(double* A, int6
       for (int rr = 0; rr < 4; ++rr) S[(16 * J + r) + (c0 + q + 4 * rr) * BLD] = acc[rr];
     }
     __syncthreads();
-    // ---- phase C: m(m+1)/2 Cholesky blocks then m*(s+1) inverse blocks, round-robin over the 16 waves
-    const int nchol = m * (m + 1) / 2, ninv = m * (s + 1);
-    for (int b = wave; b < nchol + ninv; b += 16) {
-      if (b < nchol) {
-        int ii = 0;
-        while ((ii + 1) * (ii + 2) / 2 <= b) ++ii;
-        const int I = s + 1 + ii, J = s + 1 + (b - ii * (ii + 1) / 2);
-        // D'[x][y] = C_IJ[y][x]: lanes run down the rows of C_IJ (contiguous in LDS)
-        double4_t acc;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) acc[rr] = S[(16 * I + r) + (16 * J + q + 4 * rr) * BLD];
-        acc = block_mma<1>(S + 16 * J + c0 * BLD, BLD, S + 16 * I + c0 * BLD, BLD, acc);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) S[(16 * I + r) + (16 * J + q + 4 * rr) * BLD] = acc[rr];
-      } else {
-        const int e = b - nchol;
-        const int I = s + 1 + e / (s + 1), J = e % (s + 1);
-        // Y_IJ[a][b'] -= sum_k L_Is[a][k] * X_sJ[k][b'];  Y_IJ[a][b'] sits transposed at S[(16J + b') + (16I + a) * BLD]
-        double4_t acc;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) acc[rr] = S[(16 * J + r) + (16 * I + q + 4 * rr) * BLD];
-        if (J < s) acc = block_mma<1>(S + 16 * I + c0 * BLD, BLD, S + 16 * J + c0 * BLD, BLD, acc);
-        else {  // X_ss = Wd: Bop[k][b'] = Wd[k][b'] = Wd[k + b' * 16]  -> "row index contiguous" means pb[b' + k * ld] with the transposed view
-          const int l = lane;
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(16 * I + (l & 15)) + (c0 + 4 * kk + (l >> 4)) * BLD],
-                                                       Wd[(4 * kk + (l >> 4)) + (l & 15) * 16], acc, 0, 0, 1);
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) S[(16 * J + r) + (16 * I + q + 4 * rr) * BLD] = acc[rr];
+    // ---- phase C with look-ahead: m(m+1)/2 Cholesky blocks then m*(s+1) inverse blocks.  Wave 0 takes block 0 -- the
+    // next diagonal block (s+1, s+1) -- and goes straight on to phase A of step s+1 (the sequential 16-pivot sweep,
+    // the longest single piece of the kernel) while waves 1..15 work through the other blocks; nothing they touch
+    // overlaps that block, and its 16x16 inverse goes to the other Wd buffer.
+    const int total = m * (m + 1) / 2 + m * (s + 1);
+    if (wave == 0) {
+      if (s < 7) {
+        potf2_phase_c_block(S, Wd, s, c0, m, 0, lane, q, r);
+        diag16(S + (c0 + 16) + (c0 + 16) * BLD, Wd2 + ((s + 1) & 1) * 256, Wdiag + c0 + 16, info, col0 + c0 + 16);
       }
+    } else {
+      for (int b = wave; b < total; b += 15) potf2_phase_c_block(S, Wd, s, c0, m, b, lane, q, r);
     }
     __syncthreads();
   }
