@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- the GP predict step (fit + predict) on N MI355X GPUs of one node.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W
+      N = 1 runs in this process.  N > 1 without a launcher: this process (which never touches the GPU) starts
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` as a CHILD, one
+      rank per GPU over RCCL, and relays rank 0's JSON line.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W          (the driver's own launch: used as is)
 
 One "step" = one pass of the hot path over one synthetic problem: kernel fill of K + noise*I, blocked
 fp64 Cholesky, alpha and logp (the reference's GPR$new, R/GPRclass.R:127-154) followed by the pointwise
@@ -13,13 +16,19 @@ d = 8, sqexp, n* = 4^8 = 65536 -- the configuration the metric's target is quote
 is the same at every N (strong scaling).  `--workload c2|c3` select the other single-GPU configs.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant kernel, HIP
-events recorded inside the native library on the launching stream) and, at N = 1, `cpu_baseline` (the
-oracle's blocked OpenMP port on a bounded sample of the same workload).
+events recorded inside the native library on the launching stream), `parity_timed_config_normwise_err` (the
+outputs of the LAST TIMED step against an independent small-batch predict and the K alpha = y - noise alpha
+identity; the run FAILS above 1e-9) and, at N = 1, `cpu_baseline` (three CPU lines on a bounded sample).
+
+GPRC_BENCH_BACKEND=gloo: ranks exchange through gloo and share cuda:(LOCAL_RANK mod device count) -- how
+`pytest -m gpu` rehearses `--gpus 2` on a one-GPU box.  Default backend: nccl (= RCCL over xGMI).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X spec, fp64 matrix (dense); measured 77.5 by tools/microbench/mfma_f64.hip
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+PARITY_FAIL = 1e-9             # the run fails when the timed outputs are further than this from the independent values
 
 WORKLOADS = {
     # name: (n, d, kernel name, params, n_star or None -> reference grid rule)
@@ -49,7 +59,7 @@ def synth(n, d, n_star):
     X = rng.uniform(-1.0, 1.0, size=(n, d))                      # row i = point i  (== d x n column-major)
     y = 0.1 * (X ** 3).sum(1) + rng.normal(0.0, 0.1, size=n)
     if n_star is None:
-        per = math.ceil(10000 ** (1.0 / d) - 1e-9)
+        per = math.ceil(10000 ** (1.0 / d))   # R: seq(length.out = x) applies a bare ceiling()
         axes = [np.linspace(-1.0, 1.0, per)] * d
         Xs = np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(-1, d)
     else:
@@ -62,32 +72,96 @@ def step_flops(n, ns):
     return n ** 3 / 3.0 + float(n) * n * ns + 2.0 * n * n + 4.0 * n * ns
 
 
-def cpu_baseline(kname, params, d, budget_s=15.0):
-    """Oracle (blocked OpenMP port of the same algorithm) on a bounded sample of the workload."""
+# ---- CPU column ------------------------------------------------------------------------------------------------------
+def usable_cpus():
+    """(os.cpu_count() uncapped, CPUs this process may actually use: affinity mask and cgroup quota)."""
+    host = os.cpu_count() or 1
+    use = host
+    try:
+        use = min(use, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            use = min(use, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return host, max(1, use)
+
+
+def cpu_baseline(kname, params, d, budget_1t_s=18.0):
+    """Three CPU lines on the SAME inputs and the same n (= n*), the largest power of two whose 1-thread run fits the
+    budget: the oracle's blocked port with all usable cores and with 1 thread (R's default BLAS/LAPACK is single
+    threaded), and LAPACK dpotrf + dtrtrs through scipy/OpenBLAS when importable."""
     from oracle import oracle as orc
-    cores = min(16, os.cpu_count() or 1)
-    orc.set_threads(cores)
+    host, cores = usable_cpus()
     kid = KERNEL_IDS[kname]
 
-    def run(n, ns):
+    def run_port(threads, n, ns):
+        orc.set_threads(threads)
         X, y, Xs = synth(n, d, ns)
         t0 = time.perf_counter()
         r = orc.gpr_fit_predict_blocked(kid, params, X.T, y, 0.1, Xs.T)
         dt = time.perf_counter() - t0
         assert r["info"] == 0
-        return dt
+        return dt, r
 
-    t_cal = run(1024, 1024)
-    rate = step_flops(1024, 1024) / t_cal
+    t_cal, _ = run_port(1, 1024, 1024)
+    rate1 = step_flops(1024, 1024) / t_cal
     n = 1024
-    while n < 8192 and step_flops(2 * n, 2 * n) / rate < budget_s:
+    while n < 8192 and step_flops(2 * n, 2 * n) / rate1 < budget_1t_s:
         n *= 2
-    dt = run(n, n) if n > 1024 else t_cal
-    return {"value": round(step_flops(n, n) / dt * 1e-12, 5), "unit": "TFLOP/s", "cores": cores, "kind": "port",
-            "sample": f"oracle_gpr_fit_predict_blocked (OpenMP, {cores} threads) on n={n}, n*={n}, d={d}, {kname}: {dt:.2f} s"}
+    fl = step_flops(n, n)
+    lines = []
+    dt_all, r_all = run_port(cores, n, n)
+    lines.append({"name": "oracle_port_all_cores", "kind": "port", "threads": cores, "seconds": round(dt_all, 3),
+                  "value": round(fl / dt_all * 1e-12, 5), "unit": "TFLOP/s"})
+    dt_1, _ = run_port(1, n, n) if n > 1024 else (t_cal, None)
+    lines.append({"name": "oracle_port_1_thread", "kind": "port", "threads": 1, "seconds": round(dt_1, 3),
+                  "value": round(fl / dt_1 * 1e-12, 5), "unit": "TFLOP/s"})
+    orc.set_threads(cores)
+    try:   # LAPACK sanity line: numpy kernel fill (direct (x-y)^2 sums) + dpotrf + dpotrs + dtrtrs
+        import scipy.linalg as sl
+        X, y, Xs = synth(n, d, n)
+
+        def kern(A, B):
+            D = np.zeros((A.shape[0], B.shape[0]))
+            for r in range(d):
+                D += (A[:, r, None] - B[None, :, r]) ** 2
+            return np.exp(-D / (2 * params[0] ** 2)) if kname == "sqrexp" else (1 + D / (2 * params[1] * params[0] ** 2)) ** (-params[1])
+
+        t0 = time.perf_counter()
+        K = kern(X, X)
+        K[np.diag_indices(n)] += 0.1
+        L = sl.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+        alpha = sl.cho_solve((L, True), y, check_finite=False)
+        Ks = kern(X, Xs)
+        mean = Ks.T @ alpha
+        v = sl.solve_triangular(L, Ks, lower=True, overwrite_b=True, check_finite=False)
+        var = 1.0 - np.einsum("ij,ij->j", v, v)
+        dt_s = time.perf_counter() - t0
+        err = max(float(np.abs(mean - r_all["mean"]).max() / np.abs(r_all["mean"]).max()),
+                  float(np.abs(var - r_all["var"]).max() / np.abs(r_all["var"]).max()))
+        try:
+            from threadpoolctl import threadpool_info
+            blas_threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+        except Exception:
+            blas_threads = None
+        lines.append({"name": "scipy_openblas_dpotrf_dtrtrs", "kind": "lapack", "threads": blas_threads, "seconds": round(dt_s, 3),
+                      "value": round(fl / dt_s * 1e-12, 5), "unit": "TFLOP/s", "normwise_diff_vs_port": err})
+    except ImportError:
+        pass
+    # best of the three: all are CPU restatements of the reference algorithm ("port"); the LAPACK line is the closest to
+    # what R itself executes (chol() = dpotrf), with a triangular solve where R runs dgesv
+    best = max(lines, key=lambda ln: ln["value"])
+    return {"value": best["value"], "unit": "TFLOP/s", "cores": best["threads"] or cores, "kind": "port",
+            "host_cpu_count": host, "usable_cpus": cores,
+            "sample": f"fit + pointwise predict on n={n}, n*={n}, d={d}, {kname} (same synthetic inputs for every line); best line: {best['name']} ({best['seconds']} s)",
+            "lines": lines}
 
 
-def parity_gate(eng_factory, comm, dev_ops_cls):
+def parity_gate(eng_factory, comm):
     """Small fit+predict through the same engine against the oracle (normwise 1e-10) before timing."""
     from oracle import oracle as orc
     n, d, ns = 1536, 8, 512
@@ -108,6 +182,69 @@ def parity_gate(eng_factory, comm, dev_ops_cls):
     return max(e1, e2)
 
 
+def timed_config_parity(eng, ops, bufs, X, y, Xs, lo, hi, mean, var, noise=0.1, rows=512):
+    """Independent values for the outputs of the LAST TIMED step (this rank's slice [lo, hi) of the grid):
+      (a) `rows` strided rows predicted again in a separate small batch -- M = rows instead of M = hi - lo, so a
+          different panel-group schedule of the solve (bit-identical by construction, compared normwise AND bitwise);
+      (b) the size-independent identity K alpha = y - noise alpha read off a small-batch predict at `rows` TRAINING
+          inputs (first, middle and last panels), which involves every panel of the timed factor, both triangular
+          solves, the K*^T fill and the mean reduction, plus 0 < var < noise there.
+    (a) ties the big-batch outputs to the small-batch path, (b) ties that path to the mathematics."""
+    n = X.shape[0]
+    m = hi - lo
+    out = {"rows": 0, "bitwise_equal": True, "normwise_err": 0.0, "identity_err": 0.0, "var_bounds_ok": True}
+    if m > 0:
+        idx = np.unique(np.linspace(0, m - 1, min(rows, m)).astype(np.int64))
+        sub = ops.from_host(Xs[lo:hi][idx])
+        ms, vs = ops.zeros(idx.size), ops.zeros(idx.size)
+        eng.predict_local(bufs["X"], bufs["y"], sub, idx.size, ms, vs)
+        ms, vs = ops.to_host(ms), ops.to_host(vs)
+        e = max(float(np.abs(mean[idx] - ms).max() / max(np.abs(ms).max(), 1e-300)),
+                float(np.abs(var[idx] - vs).max() / max(np.abs(vs).max(), 1e-300)))
+        out.update(rows=int(idx.size), normwise_err=e,
+                   bitwise_equal=bool(np.array_equal(mean[idx], ms) and np.array_equal(var[idx], vs)))
+    third = max(rows // 3, 1)
+    tidx = np.unique(np.r_[0:min(third, n), max(n // 2 - third // 2, 0):min(n // 2 + third // 2, n), max(n - third, 0):n])
+    sub = ops.from_host(X[tidx])
+    mt, vt = ops.zeros(tidx.size), ops.zeros(tidx.size)
+    eng.predict_local(bufs["X"], bufs["y"], sub, tidx.size, mt, vt)
+    mt, vt = ops.to_host(mt), ops.to_host(vt)
+    alpha = ops.to_host(eng.alpha)[:n]
+    want = (y - noise * alpha)[tidx]
+    out["identity_err"] = float(np.abs(mt - want).max() / max(np.abs(want).max(), 1e-300))
+    out["var_bounds_ok"] = bool((vt > 0).all() and (vt < noise).all())
+    return out
+
+
+# ---- launching -------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    """--gpus N > 1 without a launcher: start the N ranks as fresh child processes.  THIS process has made no HIP call
+    (torch is not even imported), and nothing is exec'd: the launcher is a child whose exit code we return."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if proc.returncode != 0 or line is None:
+        raise SystemExit(proc.returncode or 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,29 +256,44 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        raise SystemExit("bench.py: --gpus >= 1, --steps >= 1, --warmup >= 0")
 
-    import torch
-    import gprc_amd
-    from gprc_amd import _native as nat
-    from gprc_amd.distributed import DistributedGPR, HipOps, SingleComm, TorchComm
-
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args, sys.argv[1:])       # before `import torch`: the parent never initialises the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for a different N")
+
+    import torch
+    import gprc_amd  # noqa: F401
+    from gprc_amd import _native as nat
+    from gprc_amd.distributed import DistributedGPR, HipOps, SingleComm, TorchComm
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the gprc native path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    backend = os.environ.get("GPRC_BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit("GPRC_BENCH_BACKEND must be nccl or gloo")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, {ndev} visible (GPRC_BENCH_BACKEND=gloo shares one)")
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
     use_dist = world > 1 or os.environ.get("GPRC_FORCE_DIST") == "1"   # FORCE_DIST: exercise the RCCL path with one rank
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
         comm = TorchComm()
         # panel broadcast: RCCL's rooted broadcast vs scatter + all-gather, timed once on this node (GPRC_BCAST pins it)
         comm.calibrate(lambda c: torch.empty(c, dtype=torch.float64, device="cuda"), torch.cuda.synchronize)
     else:
         comm = SingleComm()
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
 
     n, d, kname, params, n_star = WORKLOADS[args.workload]
     if args.ntrain:
@@ -150,7 +302,7 @@ def main():
         n_star = args.nstar
 
     def make_engine(n_, d_, kname_, params_, X, y, Xs):
-        ops = HipOps(local_rank, KERNEL_IDS[kname_], params_, d_, n_, 0.1)
+        ops = HipOps(device, KERNEL_IDS[kname_], params_, d_, n_, 0.1)
         eng = DistributedGPR(ops, comm)
         g = ops.geom
         ypad = np.zeros(g.n_pad)
@@ -166,7 +318,7 @@ def main():
 
     gate_err = None
     if not args.no_parity_gate:
-        gate_err = parity_gate(make_engine, comm, HipOps)
+        gate_err = parity_gate(make_engine, comm)
 
     X, y, Xs = synth(n, d, n_star)
     ns = Xs.shape[0]
@@ -194,6 +346,22 @@ def main():
         comm.barrier()
         torch.cuda.synchronize()
 
+    def all_max(values):
+        if not use_dist:
+            return values
+        t = torch.tensor(values, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return [float(v) for v in t.cpu()]
+
+    def all_gather_rows(values):
+        """values (a short list of floats) of every rank -> [[rank 0's], [rank 1's], ...]"""
+        if not use_dist:
+            return [list(values)]
+        t = torch.tensor(values, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        outs = [torch.empty_like(t) for _ in range(world)]
+        torch.distributed.all_gather(outs, t)
+        return [[float(v) for v in o.cpu()] for o in outs]
+
     for _ in range(args.warmup):
         step()
     nat.lib().gprc_prof_reset()
@@ -206,14 +374,17 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     nat.lib().gprc_prof_enable(0)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = all_max([elapsed])[0]
 
     mean = ops.to_host(bufs["mean"])[: hi - lo]
     var = ops.to_host(bufs["var"])[: hi - lo]
     sane = bool(np.isfinite(mean).all() and np.isfinite(var).all() and (var > -1e-8).all())
+    tp = timed_config_parity(eng, ops, bufs, X, y, Xs, lo, hi, mean, var)
+    par_err, id_err, bad = all_max([tp["normwise_err"], tp["identity_err"],
+                                    0.0 if (sane and tp["var_bounds_ok"] and tp["bitwise_equal"]) else 1.0])
+    parity_ok = bool(par_err <= PARITY_FAIL and id_err <= PARITY_FAIL and bad == 0.0)
+
+    phases = all_gather_rows([sum(a.elapsed_time(b) for a, b, _ in marks) / len(marks), sum(b.elapsed_time(c) for _, b, c in marks) / len(marks)])
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -226,20 +397,23 @@ def main():
             kernels[name] = {"launches": r["count"], "ms_total": round(r["ms"], 3), "avg_ms": round(r["ms"] / r["count"], 4),
                              "tflops": round(r["flops"] / r["ms"] * 1e-9, 3) if r["ms"] > 0 else None,
                              "gbs": round(r["bytes"] / r["ms"] * 1e-6, 1) if r["ms"] > 0 else None}
-        dom_name = max(("solve_left", "solve_update_k512", "trailing_update"), key=lambda k: prof[k]["ms"])
+        dom_name = max(("solve_left", "solve_update_k512", "trailing_update", "trailing_left"), key=lambda k: prof[k]["ms"])
         dom = prof[dom_name]
         achieved = dom["flops"] / dom["ms"] * 1e-9 if dom["ms"] > 0 else 0.0
-        symbol = {"solve_left": "solve_left_kernel", "solve_update_k512": "gemm_nt_kernel<5>", "trailing_update": "trailing_kernel"}[dom_name]
+        symbol = {"solve_left": "solve_left_kernel", "solve_update_k512": "gemm_nt_kernel<5>", "trailing_update": "trailing_kernel",
+                  "trailing_left": "trailing_range_kernel"}[dom_name]
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
         # comes from the separate rocprofv3 --pmc passes of the same command stored under profiles/ (see the JSON's
         # `source`), per launch and corrected as MI355X_MICROARCH.md prescribes; null when no matching profile.
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_c4_pmc_traffic.json")))
-            if pm["kernel"] == symbol and pm["workload"] == args.workload and pm["n_gpus"] == world and not args.ntrain and not args.nstar:
-                traffic = pm["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, traffic_src = None, None
+        for cand in ("r02_c4_pmc_traffic.json", "r01_c4_pmc_traffic.json"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                if pm["kernel"] == symbol and pm["workload"] == args.workload and pm["n_gpus"] == world and not args.ntrain and not args.nstar:
+                    traffic, traffic_src = pm["traffic_bytes_per_launch"], "profiles/" + cand
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         out = {
             "metric": "GPR predict-step achieved fp64 TFLOP/s (kernel fill + Cholesky + solves + mean/variance), n x n sqexp",
             "value": round(flops / (elapsed / args.steps) * 1e-12, 4),
@@ -254,26 +428,36 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: n={n} d={d} {kname} GPR fit+predict, n*={ns} (reference test-grid rule), noise=0.1",
-                       "n": n, "d": d, "n_star": ns, "kernel": kname, "kernel_params": params,
+                       "n": n, "d": d, "n_star": ns, "kernel": kname, "kernel_params": params, "backend": backend if use_dist else None,
                        "parallelism": f"1-D block-cyclic 512-column panels over {world} GPU(s), test points sliced"},
             "roofline": {"bound": "mfma", "kernel": symbol, "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "bytes per launch (PMC, separate pass)", "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["count"], 1)),
+                         "traffic_unit": "bytes per launch (PMC, separate pass)", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["count"], 1)),
                          "launches": dom["count"], "avg_launch_ms": round(dom["ms"] / max(dom["count"], 1), 4)},
-            "phases_ms": {"fit_F1_F3": round(sum(a.elapsed_time(b) for a, b, _ in marks) / len(marks), 3),
-                          "predict_P1_P3": round(sum(b.elapsed_time(c) for _, b, c in marks) / len(marks), 3)},
+            "phases_ms": {"fit_F1_F3": round(max(p[0] for p in phases), 3), "predict_P1_P3": round(max(p[1] for p in phases), 3),
+                          "per_rank": [{"rank": r, "fit_F1_F3": round(p[0], 3), "predict_P1_P3": round(p[1], 3)} for r, p in enumerate(phases)]},
             "kernels": kernels,
             "frac_of_fp64_peak_end_to_end": round(flops / (elapsed / args.steps) * 1e-12 / (FP64_MFMA_PEAK_TFLOPS * world), 4),
             "panel_broadcast": getattr(comm, "calibration", None) or {"choice": getattr(comm, "choice", None)},
             "parity_gate_normwise_err": gate_err,
+            "parity_timed_config_normwise_err": par_err,
+            "parity_timed_config": {"rows_rank0": tp["rows"], "bitwise_equal_to_small_batch": bad == 0.0 or tp["bitwise_equal"],
+                                    "identity_K_alpha_normwise_err": id_err, "fail_above": PARITY_FAIL, "ok": parity_ok},
             "outputs_sane": sane,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kname, params, d)
-        print(json.dumps(out), flush=True)
+        if parity_ok:
+            print(json.dumps(out), flush=True)
+        else:   # a fast step with wrong outputs is not a measurement: no JSON line on stdout
+            print("bench.py: PARITY FAILURE of the timed configuration: " + json.dumps(out["parity_timed_config"]) +
+                  f" normwise_err={par_err}", file=sys.stderr, flush=True)
     ops.close()
     if use_dist:
         torch.distributed.destroy_process_group()
+    if not parity_ok:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

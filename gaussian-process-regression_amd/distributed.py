@@ -120,33 +120,37 @@ class TorchComm:
         count -= count % self.world
         buf = make_buffer(count)
         ref = make_buffer(count)
+        if self.dist.get_backend() != "nccl" and buf.is_cuda:
+            # gloo moving DEVICE tensors (ranks sharing one GPU in the rehearsal runs) has no scatter /
+            # all_gather_into_tensor: nothing to choose between.  Decided from the backend name and the buffer's device,
+            # identically on every rank, before any collective.
+            self.calibration = {"choice": self.choice, "skipped": "backend " + self.dist.get_backend() + " on device tensors"}
+            return self.choice
         times, ok = {}, True
+        # No try/except around the collectives: an error raised by ONE rank inside a collective must end that rank
+        # (the launcher then tears the job down) -- swallowing it would leave the other ranks blocked in the collective.
         for mode in ("broadcast", "scatter_allgather"):
             self.choice = mode
-            try:
-                for it in range(reps + 1):
-                    if it == 1:
-                        sync(); self.dist.barrier(); t0 = time.perf_counter()
-                    src = it % self.world
-                    if self.rank == src:
-                        buf.copy_(torch.arange(count, dtype=buf.dtype, device=buf.device) * (it + 1))
-                    else:
-                        buf.zero_()
-                    self.broadcast(buf, src)
-                sync()
-                times[mode] = (time.perf_counter() - t0) / reps
-                if mode == "broadcast":
-                    ref.copy_(buf)
+            for it in range(reps + 1):
+                if it == 1:
+                    sync(); self.dist.barrier(); t0 = time.perf_counter()
+                src = it % self.world
+                if self.rank == src:
+                    buf.copy_(torch.arange(count, dtype=buf.dtype, device=buf.device) * (it + 1))
                 else:
-                    ok = bool(torch.equal(ref, buf))
-            except RuntimeError:
-                ok = False
-                times[mode] = float("inf")
+                    buf.zero_()
+                self.broadcast(buf, src)
+            sync()
+            times[mode] = (time.perf_counter() - t0) / reps
+            if mode == "broadcast":
+                ref.copy_(buf)
+            else:
+                ok = bool(torch.equal(ref, buf))
         stat = torch.tensor([times["broadcast"], times["scatter_allgather"], 0.0 if ok else 1.0], dtype=torch.float64, device=buf.device)
         self.dist.all_reduce(stat, op=self.dist.ReduceOp.MAX)      # slowest rank decides; any mismatch vetoes
         tb, ts, bad = (float(x) for x in stat.cpu())
         self.choice = "scatter_allgather" if (bad == 0.0 and ts < 0.9 * tb) else "broadcast"
-        self.calibration = {"broadcast_ms": round(tb * 1e3, 3), "scatter_allgather_ms": round(ts * 1e3, 3) if ts != float("inf") else None,
+        self.calibration = {"broadcast_ms": round(tb * 1e3, 3), "scatter_allgather_ms": round(ts * 1e3, 3),
                             "doubles": count, "agree": bad == 0.0, "choice": self.choice}
         return self.choice
 

@@ -76,7 +76,7 @@ def _apply_cols(M, func):
 
 def _grid(lim, test_size, ctx=None):
     D = lim.shape[0]
-    per = int(math.ceil(test_size ** (1.0 / D) - 1e-9))          # seq(length.out = fractional) rounds up
+    per = int(math.ceil(test_size ** (1.0 / D)))                 # seq.default: length.out <- ceiling(length.out), a bare ceiling
     return combine_all([np.linspace(lim[i, 0], lim[i, 1], per) for i in range(D)], ctx=ctx)
 
 

@@ -85,3 +85,26 @@ def test_two_ranks_one_gpu_gloo(tmp_path, world, n):
         assert np.array_equal(o["mean"], ref[lo:hi, 0]) and np.array_equal(o["var"], ref[lo:hi, 1])
     for o in outs[1:]:
         assert np.array_equal(o["packed"], outs[0]["packed"])   # the factor is replicated on every rank
+
+
+def test_bench_gpus2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent (which never touches the GPU) starts two rank processes
+    and relays rank 0's JSON line.  GPRC_BENCH_BACKEND=gloo lets both ranks share cuda:0 on a one-GPU box (RCCL wants a
+    device per rank; the 2/4/8-device RCCL runs are the driver's).  The line must be an N = 2 line, carry the panel
+    exchange record, per-rank phases and the parity of the timed outputs."""
+    import json
+    import subprocess
+    env = dict(os.environ, GPRC_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "c2",
+                        "--ntrain", "2300", "--nstar", "1100", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["backend"] == "gloo" and out["scaling"] == "strong"
+    assert out["panel_broadcast"]["choice"] in ("broadcast", "scatter_allgather")
+    assert [p["rank"] for p in out["phases_ms"]["per_rank"]] == [0, 1]
+    assert out["parity_timed_config"]["ok"] and out["parity_timed_config_normwise_err"] <= 1e-9
+    assert out["parity_gate_normwise_err"] <= TOL and out["value"] > 0

@@ -219,3 +219,15 @@ def test_simulation_host_pieces():
     if not gpu_available():
         with pytest.raises(GprcError, match="no CPU fallback"):
             gprc_amd.combine_all([[0.0, 1.0], [2.0, 3.0]])
+
+
+def test_bench_refuses_a_world_size_it_was_not_asked_for():
+    """bench.py --gpus N must never emit a line for a different N (round-1 finding: --gpus 8 under WORLD_SIZE=1 measured
+    one GPU).  The check runs before torch or the GPU are touched."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "refusing" in r.stderr and not r.stdout.strip()
