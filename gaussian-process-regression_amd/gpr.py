@@ -46,8 +46,9 @@ class GPR:
 
     def __init__(self, X, y, noise=0, k=None, cov_names=None, *, ctx=None):
         if k is None:
-            # the reference default: k = fit(X, y, noise, cov_names)$func (R/GPRclass.R:127).  fit() here covers the
-            # Brent-optimised kernels; with the full default list it raises NotImplementedError for the BFGS ones.
+            # the reference default: k = fit(X, y, noise, cov_names)$func (R/GPRclass.R:127); all six kernels of the
+            # default list are covered (Brent for the one-parameter kernels and the polynomial degree loop, vmmin/BFGS
+            # with the reference's dens_deriv for gammaexp and rationalquadratic).
             from .fit import fit as _fit
             k = _fit(X, y, noise, cov_names, ctx=ctx)["func"]
         Xa = np.asarray(X)

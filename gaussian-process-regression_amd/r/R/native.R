@@ -80,14 +80,24 @@ covariance_matrix <- function(A, B, covariance_function) {
 }
 
 # fit(): the two closures optim() is given (R/fit.R:117-139), native branch.  `id` is the kernel id of cov_dict[[cov]]$func
-.dens_native <- function(id, X, y, noise) function(v) .Call(gprc_R_log_marginal, id, as.double(v), X, as.double(y), as.double(noise))
-.dens_deriv_native <- function(id, X, y) function(v) .Call(gprc_R_fit_gradient, id, as.double(v), X, as.double(y))
+# (X is coerced ONCE, outside the closures: REAL() on an integer matrix would error or read garbage in the shim)
+.dens_native <- function(id, X, y, noise) {
+  storage.mode(X) <- "double"
+  y <- as.double(y)
+  function(v) .Call(gprc_R_log_marginal, id, as.double(v), X, y, as.double(noise))
+}
+.dens_deriv_native <- function(id, X, y) {
+  storage.mode(X) <- "double"
+  y <- as.double(y)
+  function(v) .Call(gprc_R_fit_gradient, id, as.double(v), X, y)
+}
 
 # multivariate_normal (R/GPRclass.R:360-370), native branch: rnorm() stays in R, the factorisation and L %*% Z move
 multivariate_normal <- function(n, mean, covariance, tol = 1e-6) {
   stopifnot(length(mean) == nrow(covariance))
   Z <- matrix(rnorm(n * length(mean), 0, 1), nrow = length(mean))
   if (!gprc_native_available()) return(drop(mean) + .mvn_factor_R(covariance, tol) %*% Z)   # the original lines :362-368
+  storage.mode(covariance) <- "double"                                                       # keeps dim(); an integer matrix must not reach REAL()
   .Call(gprc_R_mvn_sample, as.double(mean), covariance, as.double(tol), Z)
 }
 

@@ -26,8 +26,11 @@ static void model_finalizer(SEXP ptr) {
   if (m) { gprc_model_free(m); R_ClearExternalPtr(ptr); }
 }
 
-static SEXP wrap_model(gprc_model* m) {
-  SEXP ptr = PROTECT(R_MakeExternalPtr(m, Rf_install("gprc_model"), R_NilValue));
+/* An EMPTY external pointer with the finalizer already registered.  Every fit entry point creates it (and every other R
+ * object it returns) BEFORE the native fit runs and stores the model in it with R_SetExternalPtrAddr -- which does not
+ * allocate -- straight after: an R allocation that longjmps can then never strand a fitted model (device memory). */
+static SEXP new_model_ptr(void) {
+  SEXP ptr = PROTECT(R_MakeExternalPtr(NULL, Rf_install("gprc_model"), R_NilValue));
   R_RegisterCFinalizerEx(ptr, model_finalizer, TRUE);
   UNPROTECT(1);
   return ptr;
@@ -53,24 +56,35 @@ SEXP gprc_R_kernel_matrix(SEXP kernel, SEXP params, SEXP A, SEXP B) {
 SEXP gprc_R_gpr_fit(SEXP kernel, SEXP params, SEXP X, SEXP y, SEXP noise) {
   const int64_t d = Rf_nrows(X), n = Rf_ncols(X);
   gprc_model* m = NULL;
-  double noise_used = 0.0;
+  double noise_used = 0.0, logp = 0.0;
   int attempts = 0;
+  /* everything R allocates for the result exists before the model does (see new_model_ptr) */
+  SEXP res = PROTECT(Rf_allocVector(VECSXP, 5));
+  SEXP ptr = new_model_ptr();
+  SET_VECTOR_ELT(res, 0, ptr);
+  SEXP alpha = Rf_allocVector(REALSXP, (R_xlen_t)n);
+  SET_VECTOR_ELT(res, 3, alpha);
+  SEXP s_noise = Rf_allocVector(REALSXP, 1), s_logp, s_att;
+  SET_VECTOR_ELT(res, 1, s_noise);
+  s_att = Rf_allocVector(INTSXP, 1);
+  SET_VECTOR_ELT(res, 2, s_att);
+  s_logp = Rf_allocVector(REALSXP, 1);
+  SET_VECTOR_ELT(res, 4, s_logp);
   int rc = gprc_gpr_fit_retry(ctx(), Rf_asInteger(kernel), REAL(params), LENGTH(params), REAL(X), d, n, REAL(y), Rf_asReal(noise), &m,
                               &noise_used, &attempts);
-  if (rc == GPRC_ERR_NOT_PD)
-    Rf_error("Inputs lead to non positive definite covariance matrix. Try using a larger noise or a smaller lengthscale.");
-  if (rc != 0) Rf_error("gprc: %s", gprc_last_error());
-  SEXP res = PROTECT(Rf_allocVector(VECSXP, 5));
-  SET_VECTOR_ELT(res, 0, wrap_model(m));
-  SET_VECTOR_ELT(res, 1, Rf_ScalarReal(noise_used));
-  SET_VECTOR_ELT(res, 2, Rf_ScalarInteger(attempts));
-  SEXP alpha = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t)n));
-  double logp = 0.0;
+  if (rc != 0) {
+    UNPROTECT(1);
+    if (rc == GPRC_ERR_NOT_PD)
+      Rf_error("Inputs lead to non positive definite covariance matrix. Try using a larger noise or a smaller lengthscale.");
+    Rf_error("gprc: %s", gprc_last_error());
+  }
+  R_SetExternalPtrAddr(ptr, m);   /* owned by the finalizer from here on; no allocation happened in between */
   gprc_gpr_get_alpha(m, REAL(alpha));
   gprc_gpr_get_logp(m, &logp);
-  SET_VECTOR_ELT(res, 3, alpha);
-  SET_VECTOR_ELT(res, 4, Rf_ScalarReal(logp));
-  UNPROTECT(2);
+  REAL(s_noise)[0] = noise_used;
+  INTEGER(s_att)[0] = attempts;
+  REAL(s_logp)[0] = logp;
+  UNPROTECT(1);
   return res;
 }
 
@@ -115,20 +129,29 @@ SEXP gprc_R_gpc_fit(SEXP kernel, SEXP params, SEXP X, SEXP y, SEXP epsilon) {
   const int64_t d = Rf_nrows(X), n = Rf_ncols(X);
   gprc_model* m = NULL;
   int iters = 0;
+  double logq = 0.0;
+  SEXP res = PROTECT(Rf_allocVector(VECSXP, 4));   /* all R allocations first (see new_model_ptr) */
+  SEXP ptr = new_model_ptr();
+  SET_VECTOR_ELT(res, 0, ptr);
+  SEXP f = Rf_allocVector(REALSXP, (R_xlen_t)n);
+  SET_VECTOR_ELT(res, 1, f);
+  SEXP s_logq = Rf_allocVector(REALSXP, 1);
+  SET_VECTOR_ELT(res, 2, s_logq);
+  SEXP s_it = Rf_allocVector(INTSXP, 1);
+  SET_VECTOR_ELT(res, 3, s_it);
   int rc = gprc_gpc_fit(ctx(), Rf_asInteger(kernel), REAL(params), LENGTH(params), REAL(X), d, n, REAL(y), Rf_asReal(epsilon), 0,
                         GPRC_GPC_REFERENCE_STOP, &m, &iters);
-  if (rc == GPRC_ERR_DIVERGED) Rf_error("Apparently does not converge.");
-  if (rc != 0) Rf_error("gprc: %s", gprc_last_error());
-  SEXP res = PROTECT(Rf_allocVector(VECSXP, 4));
-  SET_VECTOR_ELT(res, 0, wrap_model(m));
-  SEXP f = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t)n));
-  double logq = 0.0;
+  if (rc != 0) {
+    UNPROTECT(1);
+    if (rc == GPRC_ERR_DIVERGED) Rf_error("Apparently does not converge.");
+    Rf_error("gprc: %s", gprc_last_error());
+  }
+  R_SetExternalPtrAddr(ptr, m);
   gprc_gpc_get_f_hat(m, REAL(f));
   gprc_gpc_get_logq(m, &logq);
-  SET_VECTOR_ELT(res, 1, f);
-  SET_VECTOR_ELT(res, 2, Rf_ScalarReal(logq));
-  SET_VECTOR_ELT(res, 3, Rf_ScalarInteger(iters));
-  UNPROTECT(2);
+  REAL(s_logq)[0] = logq;
+  INTEGER(s_it)[0] = iters;
+  UNPROTECT(1);
   return res;
 }
 

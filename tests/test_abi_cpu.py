@@ -64,3 +64,23 @@ def test_product_never_touches_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
     out = subprocess.check_output(["ldd", nat.LIB_PATH], text=True)
     assert "oracle" not in out
+
+
+def test_call_shim_type_checks_against_the_real_header():
+    """The `.Call` shim (r/src/gprc_call_shim.c) cannot be built here (no R toolchain), but every call it makes into the
+    library can be type-checked against the REAL include/gprc_native.h: gcc -fsyntax-only over the shim with
+    tests/r_api_decls/ (prototypes of the few R C-API functions it uses; a harness, not R) in place of R's headers.
+    Catches argument-count / type drift between the shim and the C ABI; it does not run anything."""
+    shim = os.path.join(ROOT, "gaussian-process-regression_amd", "r", "src", "gprc_call_shim.c")
+    subprocess.check_call(["gcc", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-cast-function-type",
+                           "-I", os.path.join(ROOT, "tests", "r_api_decls"), "-I", os.path.join(ROOT, "include"), shim])
+    text = open(shim).read()
+    registered = dict(re.findall(r'\{"(gprc_R_[a-z_A-Z]+)", \(DL_FUNC\)&\1, (\d+)\}', text))
+    for name, nargs in registered.items():   # the registration table's arity matches each definition
+        m = re.search(r"SEXP " + name + r"\(([^)]*)\)", text)
+        assert m, name
+        arity = 0 if m.group(1).strip() == "void" else m.group(1).count("SEXP")
+        assert arity == int(nargs), (name, arity, nargs)
+    native_r = open(os.path.join(ROOT, "gaussian-process-regression_amd", "r", "R", "native.R")).read()
+    for name in re.findall(r"\.Call\((gprc_R_[a-zA-Z_]+)", native_r):     # every .Call target exists in the shim
+        assert name in registered, name

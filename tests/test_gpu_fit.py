@@ -1,5 +1,5 @@
-"""fit() (reference R/fit.R:110-169): the native objective `dens` against the oracle, the four
-reference expectations of tests/testthat/test-fit.R:12-15 that involve Brent-optimised kernels, and the optimum
+"""fit() (reference R/fit.R:110-169): the native objective `dens` against the oracle, the reference's
+own fixture tests/testthat/test-fit.R:12-17 with its full six-kernel list (recorded outcomes), and the optimum
 against an independent optimiser on the oracle's objective.  Parity status of fit(): unpinned by the reference (it
 only checks the winning kernel NAME)."""
 import numpy as np
@@ -30,33 +30,40 @@ def test_dens_is_the_log_marginal_likelihood():
         dens(np.array([[2.0, 0.1, 0.5]]), np.array([1.0, 2.0, 3.0]), 0.0, "polynomial", [-1.0, 1.0])
 
 
-def test_reference_fit_expectations_brent_kernels():
-    names = ["linear", "constant", "polynomial", "sqrexp"]        # the Brent-optimised subset of test-fit.R's list
-    assert fit(X, 3 * x, 0.05, names)["cov"] == "linear"                       # test-fit.R:12
-    assert fit(X, np.full(12, 5.0), 0.05, names)["cov"] == "constant"          # :13
-    assert fit(X, 3 * x ** 2 - 2 * x, 0.05, names)["cov"] == "polynomial"      # :14
-    # :15 expects "sqrexp" for y = 5 exp(-x^2).  Following R/fit.R line by line, the degree-2 polynomial reaches a
-    # HIGHER log marginal likelihood (-3.39 at sigma = 4.67) than the best sqrexp (-10.59 at l = 0.75) -- confirmed below
-    # with an independent optimiser on the oracle's objective -- so which.max(score) is "polynomial".  Whether the
-    # reference's own test passes cannot be checked without R (its GPC tests are stale); the winner
-    # here is asserted against the independently optimised scores instead.
-    y4 = 5 * np.exp(-x ** 2)
-    r4 = fit(X, y4, 0.05, names)
-
-    def best(kid, pars_of, lo, hi):
-        def neg(v):
-            try:
-                f = orc.gpr_fit(kid, pars_of(v), X, y4, 0.05)
-                return -f["logp"] if f["attempts"] == 1 else 1e4
-            except ArithmeticError:
-                return 1e4
-        return -minimize_scalar(neg, bounds=(lo, hi), method="bounded", options={"xatol": 1e-10}).fun
-    indep = {"linear": best(orc.LINEAR, lambda v: [v], 0, 10), "constant": best(orc.CONSTANT, lambda v: [v], 0, 10),
-             "sqrexp": best(orc.SQREXP, lambda v: [v], 0, 10),
-             "polynomial": max(best(orc.POLYNOMIAL, lambda v, p=p: [v, float(p)], 0, 5) for p in range(1, 11))}
-    assert r4["cov"] == max(indep, key=indep.get) == "polynomial"
-    for nm, sc in zip(names, r4["score"]):
-        assert abs(sc - indep[nm]) <= 1e-6 * abs(indep[nm]), nm
+def test_reference_fit_fixture_full_six_kernel_list():
+    """The one fixture the reference holds for fit(): tests/testthat/test-fit.R:1-17 -- six 12-point targets, noise
+    0.05, the FULL six-kernel list, and the NAME of the kernel expected to win each.  The native fit() is run on all
+    six lines and must reproduce the committed record tests/golden/fit_six_kernels.json (made by
+    tests/golden/make_fit_record.py: the same host driver on the CPU oracle's objective and gradient): winner,
+    parameters and the whole score vector.
+      :12-14 (linear, constant, polynomial)  HOLD.
+      :15-17 (sqrexp, gammaexp, rationalquadratic)  DO NOT: the degree-2 / degree-4 polynomial reaches a higher log
+              marginal likelihood.  That is not an optimiser artefact: the record carries, for each of these lines, the
+              SUPREMUM of the expected kernel's log marginal likelihood over its valid parameter domain found by an
+              unrelated optimiser, and it lies 7-12 nats BELOW the polynomial's score -- no search strategy can make
+              the expected kernel win which.max(score) (R/fit.R:163).  Whether the reference's own test passes cannot
+              be observed without R (its GPC tests are demonstrably stale); parity of fit() stays unpinned on these
+              three lines and the outcome is recorded rather than hidden."""
+    import json
+    import os
+    from conftest import ROOT
+    rec = json.load(open(os.path.join(ROOT, "tests", "golden", "fit_six_kernels.json")))
+    names = rec["cov_names"]
+    assert names == ["linear", "constant", "polynomial", "sqrexp", "gammaexp", "rationalquadratic"]        # test-fit.R:12-17
+    ys = [3 * x, np.full(12, 5.0), 3 * x ** 2 - 2 * x, 5 * np.exp(-x ** 2), 5 * np.exp(-x ** 5), 5 / (1 + x ** 2)]
+    holds = []
+    for case, y in zip(rec["cases"], ys):
+        r = fit(X, y, rec["noise"], names)
+        assert r["cov"] == case["winner"], case["line"]
+        assert np.allclose(r["par"], case["par"], rtol=1e-6, atol=1e-9), (case["line"], r["par"], case["par"])
+        for nm, sc in zip(names, r["score"]):
+            assert abs(sc - case["score"][nm]) <= 1e-7 * max(1.0, abs(case["score"][nm])), (case["line"], nm, sc, case["score"][nm])
+        holds.append(r["cov"] == case["expected_by_test_fit_R"])
+        if not holds[-1]:
+            sup = case["supremum_of_expected_kernel"]["logp"]
+            assert r["cov"] == "polynomial" and sup < case["score"]["polynomial"] - 5.0     # the expected kernel cannot win
+            assert case["score"][case["expected_by_test_fit_R"]] <= sup + 1e-6                # fit()'s own score respects the supremum
+    assert holds == [True, True, True, False, False, False]
 
 
 def test_fit_optimum_matches_independent_optimiser():

@@ -68,6 +68,28 @@ def test_gpc_works_reference_sign_tests():
     assert gc.predict_class(np.array([[0.0], [1.0]]))[0] < 0.5 < gc.predict_class(np.array([[-0.3], [-0.9]]))[0]
 
 
+def test_gpc_works_reference_cluster_test():
+    """tests/testthat/test-gpc.R:30-36 (the fourth sign test): two 2-D Gaussian clusters drawn with the package's own
+    multivariate_normal(n, c(+-0.5, +-0.5), diag(c(0.1, 0.1))) -- here on the device, Cholesky branch -- labelled +1 / -1,
+    k = sqrexp(l = 1); the class probability must be < 0.5 at (-0.2, -0.2) and > 0.5 at (0.2, 0.2).  The reference draws
+    unseeded (R's Mersenne-Twister stream is not reproducible here), so the expectation has to hold for any draw: six
+    seeded draws are run, each also against the oracle on the same points."""
+    from gprc_amd import multivariate_normal
+    n = 10
+    for seed in range(6):
+        rng = np.random.default_rng(seed)
+        X = np.hstack([multivariate_normal(n, [0.5, 0.5], np.diag([0.1, 0.1]), rng=rng),
+                       multivariate_normal(n, [-0.5, -0.5], np.diag([0.1, 0.1]), rng=rng)])       # cbind(...)  :32
+        y = np.repeat([1.0, -1.0], n)                                                               # :33
+        assert X.shape == (2, 2 * n) and X[:, :n].mean() > 0 > X[:, n:].mean()
+        gc = GPC.new(X, y, cov_func(sqrexp, l=1), 1e-5)                                             # :34-35 (argument order fixed)
+        assert gc.predict_class(np.array([[-0.2], [-0.2]]))[0] < 0.5 < gc.predict_class(np.array([[0.2], [0.2]]))[0]   # :36-37
+        ref = orc.gpc_fit(orc.SQREXP, [1.0], X, y, 1e-5)
+        fs, vf = orc.gpc_predict_latent(orc.SQREXP, [1.0], X, y, ref["f_hat"], ref["L"], np.array([[-0.2, 0.2], [-0.2, 0.2]]))
+        got = gc.predict_latent(np.array([[-0.2, 0.2], [-0.2, 0.2]]))
+        assert gc.iterations == ref["iters"] and nerr(got[0], fs) <= 1e-9 and nerr(got[1], vf) <= 1e-9
+
+
 # ---- committed golden vectors ------------------------------------------------------------------------
 def test_golden_closed_forms(golden):
     for c in golden.of_type("gpr_closed_form"):
@@ -337,6 +359,32 @@ def test_class_probability_kernel_against_quadrature():
     bad_mu, bad_sd, bad = np.array([0.0, 1.0]), np.array([0.0, -0.5]), np.empty(2)
     nat.check(nat.lib().gprc_class_probability(ctx.handle, bad_mu.ctypes.data, bad_sd.ctypes.data, 2, bad.ctypes.data))
     assert np.isnan(bad).all()
+
+
+def test_class_probability_divergence_is_pinned():
+    """Where predict_class(integrator="native") -- the Python default -- does NOT reproduce the reference
+    (R/GPCclass.R:116-117): for a narrow peak far from the origin, stats::integrate's dqagi on (-Inf, Inf) never samples
+    the peak and returns ~0 with a tiny error estimate (no warning), so the reference reports P ~ 0.  The device kernel
+    returns the value of the integral.  Both behaviours are asserted so the divergence cannot drift unnoticed:
+    quadpack (the reference's method, R's default tolerances) ~ 0; native == brute-force quadrature ~ sigmoid(mu)."""
+    from gprc_amd.gpc import class_probability_quadpack
+    mu = np.array([8.0, 8.0, 25.0, 6.0, -8.0, -30.0])
+    sd = np.array([0.05, 1e-3, 0.05, 1e-3, 0.05, 1e-3])
+    out = np.empty(mu.size)
+    nat.check(nat.lib().gprc_class_probability(nat.default_context().handle, mu.ctypes.data, sd.ctypes.data, mu.size, out.ctypes.data))
+    t = np.linspace(-12, 12, 400001)
+    wt = np.exp(-0.5 * t * t) / math.sqrt(2 * math.pi) * (t[1] - t[0])
+    brute = np.array([(wt / (1 + np.exp(-(m + s * t)))).sum() for m, s in zip(mu, sd)])
+    assert np.abs(out - brute).max() <= 1e-11                      # native: the integral
+    qp = class_probability_quadpack(mu, sd)                        # the reference's method
+    assert (qp[:4] < 1e-4).all() and (out[:4] > 0.997).all()       # positive side: reference ~0, truth ~1 -- they DIFFER
+    assert abs(out[0] - 0.99966423) < 1e-7 and qp[0] < 1e-30        # the case of the round-1 review: (8, 0.05)
+    assert (qp[4:] < 1e-4).all() and (out[4:] < 1e-3).all()        # negative side: both ~0 (the reference is right by accident)
+    # where dqagi does resolve the peak the two agree to integrate()'s own tolerance and better
+    mu2, sd2 = np.array([8.0, -2.5, 0.2, 6.0]), np.array([0.43, 0.43, 1.8, 7.0])
+    out2 = np.empty(4)
+    nat.check(nat.lib().gprc_class_probability(nat.default_context().handle, mu2.ctypes.data, sd2.ctypes.data, 4, out2.ctypes.data))
+    assert np.abs(out2 - class_probability_quadpack(mu2, sd2)).max() <= 1e-7
 
 
 def test_predict_class_native_matches_reference_method(golden):

@@ -212,3 +212,26 @@ def test_sampling_restatement():
     Z = rng.normal(size=(3, 4))
     out, _ = orc.multivariate_normal([1.0, 2.0, 3.0], np.diag([4.0, 9.0, 16.0]), Z)
     assert np.allclose(out, np.array([[1.0], [2.0], [3.0]]) + np.diag([2.0, 3.0, 4.0]) @ Z, rtol=0, atol=1e-15)
+
+
+def test_fit_record_is_what_the_host_driver_yields_on_the_oracle():
+    """tests/golden/fit_six_kernels.json (the recorded outcome of tests/testthat/test-fit.R:12-17 with the full six-kernel
+    list) against a fresh run of tests/golden/make_fit_record.py's recipe: the package's Brent / vmmin /
+    optim_until_error driver on the oracle's dens and dens_deriv.  Pins the host driver and the record to each other on
+    the CPU; tests/test_gpu_fit.py then holds the native objective to the same record."""
+    import importlib.util
+    import json
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("make_fit_record", os.path.join(ROOT, "tests", "golden", "make_fit_record.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rec = json.load(open(os.path.join(ROOT, "tests", "golden", "fit_six_kernels.json")))
+    x, ys = mod.targets()
+    with mod.oracle_backed_fit() as fit:
+        for case, y in zip(rec["cases"], ys):
+            r = fit(x.reshape(1, -1), y, rec["noise"], rec["cov_names"])
+            assert r["cov"] == case["winner"] and case["holds"] == (case["winner"] == case["expected_by_test_fit_R"])
+            assert np.allclose(r["par"], case["par"], rtol=1e-9, atol=1e-12)
+            assert np.allclose(r["score"], [case["score"][nm] for nm in rec["cov_names"]], rtol=1e-10, atol=1e-10)
+    assert [c["holds"] for c in rec["cases"]] == [True, True, True, False, False, False]
