@@ -131,23 +131,29 @@ def cpu_baseline(kname, params, d, budget_1t_s=18.0):
                 D += (A[:, r, None] - B[None, :, r]) ** 2
             return np.exp(-D / (2 * params[0] ** 2)) if kname == "sqrexp" else (1 + D / (2 * params[1] * params[0] ** 2)) ** (-params[1])
 
-        t0 = time.perf_counter()
-        K = kern(X, X)
-        K[np.diag_indices(n)] += 0.1
-        L = sl.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
-        alpha = sl.cho_solve((L, True), y, check_finite=False)
-        Ks = kern(X, Xs)
-        mean = Ks.T @ alpha
-        v = sl.solve_triangular(L, Ks, lower=True, overwrite_b=True, check_finite=False)
-        var = 1.0 - np.einsum("ij,ij->j", v, v)
-        dt_s = time.perf_counter() - t0
+        def lapack_step():
+            t0 = time.perf_counter()
+            K = kern(X, X)
+            K[np.diag_indices(n)] += 0.1
+            L = sl.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+            alpha = sl.cho_solve((L, True), y, check_finite=False)
+            Ks = kern(X, Xs)
+            mean = Ks.T @ alpha
+            v = sl.solve_triangular(L, Ks, lower=True, overwrite_b=True, check_finite=False)
+            var = 1.0 - np.einsum("ij,ij->j", v, v)
+            return time.perf_counter() - t0, mean, var
+
+        try:   # OpenBLAS sizes its pool from the HOST's core count (256 on the GPU node); hold it to what this job may use
+            from threadpoolctl import threadpool_limits
+            from threadpoolctl import threadpool_info
+            with threadpool_limits(limits=cores, user_api="blas"):
+                blas_threads = max([p_.get("num_threads", 1) for p_ in threadpool_info() if p_.get("user_api") == "blas"] or [1])
+                dt_s, mean, var = lapack_step()
+        except ImportError:
+            blas_threads = None
+            dt_s, mean, var = lapack_step()
         err = max(float(np.abs(mean - r_all["mean"]).max() / np.abs(r_all["mean"]).max()),
                   float(np.abs(var - r_all["var"]).max() / np.abs(r_all["var"]).max()))
-        try:
-            from threadpoolctl import threadpool_info
-            blas_threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
-        except Exception:
-            blas_threads = None
         lines.append({"name": "scipy_openblas_dpotrf_dtrtrs", "kind": "lapack", "threads": blas_threads, "seconds": round(dt_s, 3),
                       "value": round(fl / dt_s * 1e-12, 5), "unit": "TFLOP/s", "normwise_diff_vs_port": err})
     except ImportError:

@@ -327,7 +327,10 @@ int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* 
 //                  and one tile prologue instead of p; inside the group the panels update each other right-looking.
 // G is the smallest group that gives a pass (m_pad / 128) * 4 G >= 4096 tiles (eight generations of two workgroups on
 // each of 256 CUs: the partially filled last generation of long tiles stays cheap); G >= P degenerates to plain right-looking.  GPRC_SOLVE=right forces that, =left forces G = 1, =<n> G = n.
-int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt, int64_t ldv, int64_t m_pad) {
+// sspart != nullptr: the panel solve that finalises a 128-column block also leaves that block's per-row sum of squares in
+// sspart[block * m_pad + row] (n_pad / 128 blocks): colSums(v * v) without another pass over the chunk.
+int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt, int64_t ldv, int64_t m_pad,
+               double* sspart = nullptr) {
   hipStream_t s = ctx->stream;
   const int64_t P = n_pad / NB;
   const char* mode = std::getenv("GPRC_SOLVE");
@@ -347,7 +350,7 @@ int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t 
         if (j > 0)
           GPRC_TRY(launch_gemm_nt(s, vt + cj * ldv, ldv, vt + p * NB * ldv, ldv, pan + (int64_t)j * NBI, ld, m_pad, NBI, (int64_t)j * NBI, 0,
                                   PK_GEMM_INNER));
-        GPRC_TRY(launch_trsm_panel(s, vt + cj * ldv, ldv, m_pad, wblk));
+        GPRC_TRY(launch_trsm_panel(s, vt + cj * ldv, ldv, m_pad, wblk, sspart ? sspart + (cj / NBI) * m_pad : nullptr));
       }
       const int64_t right = (g1 - (p + 1)) * NB;  // the rest of the group
       if (right > 0)
@@ -513,6 +516,33 @@ int mvn_factor_dev(gprc_ctx* ctx, const double* cov_dev, int64_t ld, int64_t m, 
   GPRC_TRY(launch_gather_scale_cols(s, V.p, (int)m, permd.p, scale.p, L_dev, m));
   GPRC_HIP(hipStreamSynchronize(s));
   *method = 2;
+  return 0;
+}
+
+// doubles of partial-sum workspace per chunk row: the fill's K*^T w partials (one per 64 columns) + the solve's
+// sums of squares (one per 128 columns)
+int64_t predict_partials(int64_t n_pad) { return fill_mean_tiles(n_pad) + n_pad / NBI; }
+
+// One chunk of the pointwise predict, everything fused ("Predict epilogues"):
+//   fill K*^T chunk   + per-tile partials of K*^T w            (w = alpha; GPC: g, with the stored columns scaled by sqrt(W))
+//   vt := vt L^-T     + per-block sums of squares in the panel solves
+//   tail              mean = sum of the fill partials; var = k(x*,x*) - sum of the block sums     (R/GPRclass.R:161,164)
+// The chunk is written once by the fill and read/written only by the solve: the two row-reduction passes over it are gone.
+int predict_chunk(gprc_model* m, const double* xc, int64_t mcur, double* vt, int64_t ldv, double* part, double* kss_c,
+                  const double* colscale, double* mean_out, double* var_out) {
+  gprc_ctx* ctx = m->ctx;
+  hipStream_t s = ctx->stream;
+  const int64_t n = m->n, n_pad = m->n_pad, d = m->d, m_pad = pad_up(mcur, 128);
+  const int64_t mt = fill_mean_tiles(n_pad);
+  double* mpart = part;
+  double* sspart = part + mt * m_pad;
+  GPRC_TRY(launch_fill_cross_fused(s, m->ks, xc, mcur, m->X, n, d, vt, ldv, m_pad, n_pad, m->alpha, mpart, colscale));  // :160-161
+  GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt, ldv, m_pad, var_out ? sspart : nullptr));                       // :162
+  GPRC_TRY(launch_sum_partials(s, mpart, mt, m_pad, mcur, nullptr, mean_out));
+  if (var_out) {
+    GPRC_TRY(launch_colwise(s, m->ks, xc, xc, d, mcur, kss_c));                                                           // k(X*,X*)  :164
+    GPRC_TRY(launch_sum_partials(s, sspart, n_pad / NBI, m_pad, mcur, kss_c, var_out));
+  }
   return 0;
 }
 
@@ -718,12 +748,12 @@ int gprc_fit_gradient(gprc_ctx* ctx, int kernel, const double* params, int n_par
   const int64_t rows = chunk_rows(ctx, n_pad, n);
   double *vt = nullptr, *red = nullptr;
   GPRC_TRY(ws_get(ctx, 0, rows * n_pad, &vt));
-  GPRC_TRY(ws_get(ctx, 1, rows * rowreduce_splits(n_pad), &red));
+  GPRC_TRY(ws_get(ctx, 1, rows * predict_partials(n_pad), &red));
   for (int64_t s0 = 0; s0 < n; s0 += rows) {
     const int64_t mcur = std::min<int64_t>(rows, n - s0), m_pad = pad_up(mcur, 128);
     GPRC_TRY(launch_set_identity_rows(s, vt, m_pad, m_pad, n_pad, s0));
-    GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt, m_pad, m_pad));
-    GPRC_TRY(launch_row_reduce(s, vt, m_pad, m_pad, n_pad, nullptr, kinv.p + s0, red));  // writes m_pad entries: kinv has n_pad
+    GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt, m_pad, m_pad, red));
+    GPRC_TRY(launch_sum_partials(s, red, n_pad / NBI, m_pad, m_pad, nullptr, kinv.p + s0));  // writes m_pad entries: kinv has n_pad
   }
   GPRC_TRY(launch_deriv_rowsum(s, kernel, params[0], n_params > 1 ? params[1] : 0.0, m->X, d, n, S.p));
   std::vector<double> ha(n), hk(n), hs(2 * n);
@@ -770,7 +800,7 @@ int gprc_gpr_predict(gprc_model* m, const double* X_star, int64_t ns, int pointw
   gprc_ctx* ctx = m->ctx;
   GPRC_TRY(use_device(ctx));
   hipStream_t s = ctx->stream;
-  const int64_t n = m->n, n_pad = m->n_pad, d = m->d;
+  const int64_t n_pad = m->n_pad, d = m->d;
   In xs;
   Out mean, var;
   GPRC_TRY(xs.set(s, X_star, d * ns));
@@ -779,39 +809,26 @@ int gprc_gpr_predict(gprc_model* m, const double* X_star, int64_t ns, int pointw
 
   const int64_t rows = pointwise ? chunk_rows(ctx, n_pad, ns) : pad_up(ns, 128);
   const int64_t ldv = rows + ctx->vt_pad;  // one leading dimension for every chunk
-  struct { double* p; } vt, red, tmp;
+  struct { double* p; } vt, part, tmp;
   GPRC_TRY(ws_get(ctx, 0, ldv * n_pad, &vt.p));
-  GPRC_TRY(ws_get(ctx, 1, rows * rowreduce_splits(n_pad), &red.p));
-  GPRC_TRY(ws_get(ctx, 2, 3 * rows, &tmp.p));
-  double* mean_c = tmp.p;
-  double* ss_c = tmp.p + rows;
-  double* kss_c = tmp.p + 2 * rows;
+  GPRC_TRY(ws_get(ctx, 1, rows * predict_partials(n_pad), &part.p));
+  GPRC_TRY(ws_get(ctx, 2, rows, &tmp.p));
+  double* kss_c = tmp.p;
 
   if (pointwise) {
     for (int64_t s0 = 0; s0 < ns; s0 += rows) {
       const int64_t mcur = (ns - s0 < rows) ? ns - s0 : rows;
-      const int64_t m_pad = pad_up(mcur, 128);
-      const double* xc = xs.dev + s0 * d;
-      GPRC_TRY(launch_fill(s, m->ks, xc, mcur, m->X, n, d, vt.p, ldv, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0));  // K_star^T  :160
-      GPRC_TRY(launch_row_reduce(s, vt.p, ldv, m_pad, n_pad, m->alpha, mean_c, red.p));                      // :161
-      GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt.p, ldv, m_pad));                                 // :162
-      GPRC_TRY(launch_row_reduce(s, vt.p, ldv, m_pad, n_pad, nullptr, ss_c, red.p));                          // colSums(v*v)
-      GPRC_TRY(launch_colwise(s, m->ks, xc, xc, d, mcur, kss_c));                                               // k(X*,X*)  :164
-      GPRC_TRY(launch_sub(s, kss_c, ss_c, var.dev + s0, mcur));
-      GPRC_HIP(hipMemcpyAsync(mean.dev + s0, mean_c, sizeof(double) * mcur, hipMemcpyDeviceToDevice, s));
+      GPRC_TRY(predict_chunk(m, xs.dev + s0 * d, mcur, vt.p, ldv, part.p, kss_c, nullptr, mean.dev + s0, var.dev + s0));
     }
   } else {
     const int64_t m_pad = rows;
     struct { double* p; } cov;
     GPRC_TRY(ws_get(ctx, 3, m_pad * m_pad, &cov.p));
-    GPRC_TRY(launch_fill(s, m->ks, xs.dev, ns, m->X, n, d, vt.p, ldv, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0));
-    GPRC_TRY(launch_row_reduce(s, vt.p, ldv, m_pad, n_pad, m->alpha, mean_c, red.p));
-    GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt.p, ldv, m_pad));
+    GPRC_TRY(predict_chunk(m, xs.dev, ns, vt.p, ldv, part.p, kss_c, nullptr, mean.dev, nullptr));
     GPRC_TRY(launch_fill(s, m->ks, xs.dev, ns, xs.dev, ns, d, cov.p, m_pad, 0, m_pad, 0, m_pad, PAD_ZERO, 0.0));  // :167
     GPRC_TRY(launch_gemm_nt(s, cov.p, m_pad, vt.p, ldv, vt.p, ldv, m_pad, m_pad, n_pad, 0, PK_COV_SYRK));                  // - t(v) %*% v
     GPRC_HIP(hipMemcpy2DAsync(var.dev, sizeof(double) * ns, cov.p, sizeof(double) * m_pad, sizeof(double) * ns, ns,
                               hipMemcpyDeviceToDevice, s));
-    GPRC_HIP(hipMemcpyAsync(mean.dev, mean_c, sizeof(double) * ns, hipMemcpyDeviceToDevice, s));
     GPRC_HIP(hipStreamSynchronize(s));  // cov goes out of scope
   }
   GPRC_TRY(mean.finish(s));
@@ -965,7 +982,7 @@ int gprc_gpc_predict_latent(gprc_model* m, const double* X_star, int64_t ns, dou
   gprc_ctx* ctx = m->ctx;
   GPRC_TRY(use_device(ctx));
   hipStream_t s = ctx->stream;
-  const int64_t n = m->n, n_pad = m->n_pad, d = m->d;
+  const int64_t n_pad = m->n_pad, d = m->d;
   In xs;
   Out fs, vf;
   GPRC_TRY(xs.set(s, X_star, d * ns));
@@ -973,23 +990,13 @@ int gprc_gpc_predict_latent(gprc_model* m, const double* X_star, int64_t ns, dou
   GPRC_TRY(vf.set(Vfs_out, ns));
   const int64_t rows = chunk_rows(ctx, n_pad, ns);
   const int64_t ldv = rows + ctx->vt_pad;
-  struct { double* p; } vt, red, tmp;
+  struct { double* p; } vt, part, tmp;
   GPRC_TRY(ws_get(ctx, 0, ldv * n_pad, &vt.p));
-  GPRC_TRY(ws_get(ctx, 1, rows * rowreduce_splits(n_pad), &red.p));
-  GPRC_TRY(ws_get(ctx, 2, 3 * rows, &tmp.p));
-  double *mean_c = tmp.p, *ss_c = tmp.p + rows, *kss_c = tmp.p + 2 * rows;
-  for (int64_t s0 = 0; s0 < ns; s0 += rows) {
+  GPRC_TRY(ws_get(ctx, 1, rows * predict_partials(n_pad), &part.p));
+  GPRC_TRY(ws_get(ctx, 2, rows, &tmp.p));
+  for (int64_t s0 = 0; s0 < ns; s0 += rows) {   // R/GPCclass.R:112-115: m->alpha holds g = (y+1)/2 - P, the stored columns are sqrt(W) * K_star
     const int64_t mcur = (ns - s0 < rows) ? ns - s0 : rows;
-    const int64_t m_pad = pad_up(mcur, 128);
-    const double* xc = xs.dev + s0 * d;
-    GPRC_TRY(launch_fill(s, m->ks, xc, mcur, m->X, n, d, vt.p, ldv, 0, m_pad, 0, n_pad, PAD_ZERO, 0.0));  // R/GPCclass.R:112
-    GPRC_TRY(launch_row_reduce(s, vt.p, ldv, m_pad, n_pad, m->alpha, mean_c, red.p));                      // :113
-    GPRC_TRY(launch_scale_cols(s, vt.p, ldv, m_pad, n_pad, m->sw));                                         // sqrt(W) * K_star
-    GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt.p, ldv, m_pad));                                 // :114
-    GPRC_TRY(launch_row_reduce(s, vt.p, ldv, m_pad, n_pad, nullptr, ss_c, red.p));
-    GPRC_TRY(launch_colwise(s, m->ks, xc, xc, d, mcur, kss_c));
-    GPRC_TRY(launch_sub(s, kss_c, ss_c, vf.dev + s0, mcur));                                                  // :115
-    GPRC_HIP(hipMemcpyAsync(fs.dev + s0, mean_c, sizeof(double) * mcur, hipMemcpyDeviceToDevice, s));
+    GPRC_TRY(predict_chunk(m, xs.dev + s0 * d, mcur, vt.p, ldv, part.p, tmp.p, m->sw, fs.dev + s0, vf.dev + s0));
   }
   GPRC_TRY(fs.finish(s));
   GPRC_TRY(vf.finish(s));

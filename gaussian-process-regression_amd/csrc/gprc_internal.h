@@ -71,6 +71,10 @@ int launch_fill(hipStream_t s, const KernelSpec& ks, const double* A, int64_t nA
                 double* out, int64_t ld, int64_t row0, int64_t nrows, int64_t col0, int64_t ncols, PadMode mode,
                 double noise);
 int launch_colwise(hipStream_t s, const KernelSpec& ks, const double* x, const double* y, int64_t d, int64_t m, double* out);
+// predict chunk K(X_star, X) with the fused epilogue: per-column-tile partials of K*^T w and an optional column scale
+int64_t fill_mean_tiles(int64_t cols);
+int launch_fill_cross_fused(hipStream_t s, const KernelSpec& ks, const double* Xs, int64_t m, const double* X, int64_t n, int64_t d,
+                            double* vt, int64_t ld, int64_t m_pad, int64_t n_pad, const double* w, double* mpart, const double* colscale);
 // S[r + n*i] = sum_c deriv_i(X[,r], X[,c]; v): row sums of the parameter derivatives of K(X,X) as cov_dict$...$deriv
 // (R/fit.R:4-31) defines them; n_deriv (1 or 2) components.  Kernels: sqrexp, gammaexp, polynomial, rationalquadratic.
 int launch_deriv_rowsum(hipStream_t s, int kernel, double v0, double v1, const double* X, int64_t d, int64_t n, double* S);
@@ -80,7 +84,7 @@ int launch_set_identity_rows(hipStream_t s, double* vt, int64_t ld, int64_t rows
 // factor the 128x128 diagonal block at A (ld) in LDS, write L in place and its inverse to winv
 int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* info_dev, int col0);
 // X[M x 128] := X * W^T for lower-triangular 128x128 W (= inverse of a diagonal block of L)
-int launch_trsm_panel(hipStream_t s, double* X, int64_t ldx, int64_t M, const double* winv);
+int launch_trsm_panel(hipStream_t s, double* X, int64_t ldx, int64_t M, const double* winv, double* ssq = nullptr);
 // C[M x N] -= A[M x K] * B[N x K]^T; lower_diag >= 0: row tile r / col tile c with r + lower_diag < c is skipped
 int launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
                    int64_t M, int64_t N, int64_t K, int lower, int kind);
@@ -105,6 +109,9 @@ int launch_logp(hipStream_t s, const double* packed, int64_t n_pad, int64_t n, c
 int launch_unpack_L(hipStream_t s, const double* packed, int64_t n_pad, int64_t n, double* out, int64_t ld_out);
 // out[i] = kss[i] - ss[i]
 int launch_sub(hipStream_t s, const double* a, const double* b, double* out, int64_t n);
+// out[i] = (minuend ? minuend[i] : 0) -/+ sum_{t < nparts} part[t * stride + i], summed in t order: the tail of the fused
+// predict epilogues (mean = sum of the fill's partials; var = k(x*,x*) - sum of the solve's per-block sums of squares)
+int launch_sum_partials(hipStream_t s, const double* part, int64_t nparts, int64_t stride, int64_t rows, const double* minuend, double* out);
 // GPC vector stages (R/GPCclass.R:78-86, 99-103, 110-114)
 int launch_gpc_pre(hipStream_t s, const double* f, const double* y, int64_t n, double* sw, double* b);
 int launch_gpc_scale(hipStream_t s, const double* sw, const double* v, double* out, int64_t n);                   // out = sw*v

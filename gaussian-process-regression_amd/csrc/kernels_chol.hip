@@ -359,9 +359,14 @@ __device__ __forceinline__ const double* strip_ktile(const double* B, int64_t ld
   }
 }
 
-template <bool SET, bool SEG = false, bool SEGA = false>
+// SSQ (the predict's panel solve only): besides storing the tile, leave in ssq[0..127] the sum of squares of each of the
+// tile's 128 rows over its 128 columns -- these columns of v^T are final after this tile, so colSums(v * v)
+// (R/GPRclass.R:164) is assembled from these per-block partials and the pass that re-read the whole solved chunk is gone.
+// Fixed order: a lane's 16 columns (n, r ascending), the four lanes of a row (xor 16, xor 32), the two column waves.
+template <bool SET, bool SEG = false, bool SEGA = false, bool SSQ = false>
 __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
-                                              int64_t ldb, int K, double* smem, int64_t brow = 0, int64_t arow = 0, int kt0 = 0) {
+                                              int64_t ldb, int K, double* smem, int64_t brow = 0, int64_t arow = 0, int kt0 = 0,
+                                              double* ssq = nullptr) {
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -455,6 +460,28 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int m = 0; m < 4; ++m) Cw[m * 16 + (int64_t)(n * 16 + 4 * r) * ldc] = acc[m][n][r];
+
+  if constexpr (SSQ) {
+    double rs[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      double q = 0.0;
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q = fma(acc[m][n][r], acc[m][n][r], q);
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      rs[m] = q;
+    }
+    __syncthreads();  // every wave is past its last operand read: the staging buffers are free
+    if (fk == 0) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) smem[wc * 128 + wr * 64 + m * 16 + fr] = rs[m];
+    }
+    __syncthreads();
+    if (t < 128) ssq[t] = smem[t] + smem[128 + t];
+  }
 }
 
 // blockIdx -> logical id so that each XCD (blocks b, b+8, ... share one) owns a contiguous id range
@@ -490,10 +517,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int64_t ldc,
 
 // X[M x 128] := X * W^T (W = inverse of the diagonal block, lower triangular), in place: a workgroup
 // owns a full 128-row strip, and every load of it precedes the epilogue stores.
-__global__ __launch_bounds__(256, 2) void trsm_panel_kernel(double* X, int64_t ldx, const double* winv) {
+template <bool SSQ>
+__global__ __launch_bounds__(256, 2) void trsm_panel_kernel(double* X, int64_t ldx, const double* winv, double* ssq) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Xs = X + (int64_t)blockIdx.x * 128;
-  gemm_tile_128<true>(Xs, ldx, Xs, ldx, winv, 128, 128, smem);
+  gemm_tile_128<true, false, false, SSQ>(Xs, ldx, Xs, ldx, winv, 128, 128, smem, 0, 0, 0, SSQ ? ssq + (int64_t)blockIdx.x * 128 : nullptr);
 }
 
 // Trailing update over the packed layout: for every target panel q in {q_begin, q_begin+stride, ..}
@@ -621,7 +649,8 @@ static int ensure_gemm_attrs() {
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<PK_GEMM_INNER>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<PK_SOLVE_UPDATE>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<PK_COV_SYRK>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_panel_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_panel_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_left_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_range_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -642,12 +671,14 @@ int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, con
   return 0;
 }
 
-int launch_trsm_panel(hipStream_t s, double* X, int64_t ldx, int64_t M, const double* winv) {
+// ssq != nullptr: also ssq[i] = sum_j X_new[i][j]^2 for the M rows (the predict's fused colSums(v * v) partial of this block column)
+int launch_trsm_panel(hipStream_t s, double* X, int64_t ldx, int64_t M, const double* winv, double* ssq) {
   if (M <= 0) return 0;
   if (M % 128) { set_error("trsm_panel: M must be a multiple of 128"); return GPRC_ERR_ARG; }
   GPRC_TRY(ensure_gemm_attrs());
   ProfScope ps(s, PK_TRSM_PANEL, 1.0 * M * 128 * 128, 8.0 * 2 * M * 128);
-  hipLaunchKernelGGL(trsm_panel_kernel, dim3((unsigned)(M / 128)), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, X, ldx, winv);
+  if (ssq) hipLaunchKernelGGL(trsm_panel_kernel<true>, dim3((unsigned)(M / 128)), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, X, ldx, winv, ssq);
+  else hipLaunchKernelGGL(trsm_panel_kernel<false>, dim3((unsigned)(M / 128)), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, X, ldx, winv, ssq);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

@@ -28,6 +28,11 @@ struct FillArgs {
   int mode;
   double noise;
   KernelSpec ks;
+  // fused predict epilogue (FUSE instantiations only; R/GPRclass.R:161, R/GPCclass.R:113-114)
+  const double* w;         // mpart[tile_col][row] = sum over the tile's 64 columns of k(A_row, B_col) * w[col]   (K*^T alpha)
+  double* mpart;           // (number of column tiles) x mpart_rows
+  int64_t mpart_rows;
+  const double* colscale;  // stored value = k(.,.) * colscale[col]   (GPC: sqrt(W) * K_star); the mean uses the unscaled value
 };
 
 // base R `^` for doubles (arithmetic.c R_POW / R_pow): x^2 is x*x, the rest is libm pow
@@ -67,7 +72,11 @@ __device__ __forceinline__ double finish(double s, const KernelSpec& ks) {
   else { double l = ks.p[0], al = ks.p[1]; return r_pow(1.0 + s / (2.0 * al * (l * l)), -al); }
 }
 
-template <int KID, bool VEC2, int MODE>
+// FUSE (cross-covariance chunks of the predict only): besides storing the tile, every workgroup leaves the partial
+// product of its 128 rows with w over its 64 columns -- summed in a fixed order (a lane's 16 columns ascending, then
+// the four waves), so the mean assembled from the partials is bitwise independent of where a row sits in a chunk --
+// and may scale the stored columns (GPC).  The K*^T alpha pass over the stored matrix (one full HBM read) disappears.
+template <int KID, bool VEC2, int MODE, bool FUSE>
 __global__ __launch_bounds__(256) void fill_kernel(FillArgs a) {
   __shared__ __attribute__((aligned(16))) double As[FD][FT_R];
   __shared__ double Bs[FT_C][FD + 1];
@@ -108,37 +117,59 @@ __global__ __launch_bounds__(256) void fill_kernel(FillArgs a) {
 
   const int64_t gi0 = ti + 2 * lane;
   const int64_t row_end = a.row0 + a.nrows, col_end = a.col0 + a.ncols;
+  double m0 = 0.0, m1 = 0.0;  // FUSE: this lane's two rows times w over its 16 columns
   // interior tile: every row/column is a valid point, inside the output window, and (identity mode) off the diagonal
   const bool interior = VEC2 && ti + FT_R <= a.nA && ti + FT_R <= row_end && tj + FT_C <= a.nB && tj + FT_C <= col_end &&
                         (MODE != PAD_IDENTITY || ti + FT_R <= tj || tj + FT_C <= ti);
   if (interior) {
     double* dst = a.out + (gi0 - a.row0) + (tj + wave * 16 - a.col0) * a.ld;
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
-      *reinterpret_cast<double2*>(dst + c * a.ld) = make_double2(finish<KID>(s0[c], a.ks), finish<KID>(s1[c], a.ks));
-    return;
-  }
-#pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    const int64_t gj = tj + wave * 16 + c;
-    if (gj >= col_end) break;
-    double v0 = finish<KID>(s0[c], a.ks), v1 = finish<KID>(s1[c], a.ks);
-    if (MODE == PAD_IDENTITY) {
-      const bool jin = gj < a.nB;
-      v0 = (jin && gi0 < a.nA) ? v0 + (gi0 == gj ? a.noise : 0.0) : (gi0 == gj ? 1.0 : 0.0);
-      v1 = (jin && gi0 + 1 < a.nA) ? v1 + (gi0 + 1 == gj ? a.noise : 0.0) : (gi0 + 1 == gj ? 1.0 : 0.0);
-    } else if (MODE == PAD_ZERO) {
-      const bool jin = gj < a.nB;
-      v0 = (jin && gi0 < a.nA) ? v0 : 0.0;
-      v1 = (jin && gi0 + 1 < a.nA) ? v1 : 0.0;
+    for (int c = 0; c < 16; ++c) {
+      double v0 = finish<KID>(s0[c], a.ks), v1 = finish<KID>(s1[c], a.ks);
+      if constexpr (FUSE) {
+        const int64_t gj = tj + wave * 16 + c;
+        if (a.w) { const double wj = a.w[gj]; m0 = fma(v0, wj, m0); m1 = fma(v1, wj, m1); }
+        if (a.colscale) { const double cs = a.colscale[gj]; v0 *= cs; v1 *= cs; }
+      }
+      *reinterpret_cast<double2*>(dst + c * a.ld) = make_double2(v0, v1);
     }
-    double* dst = a.out + (gi0 - a.row0) + (gj - a.col0) * a.ld;
-    if constexpr (VEC2) {
-      if (gi0 + 1 < row_end) *reinterpret_cast<double2*>(dst) = make_double2(v0, v1);
-      else if (gi0 < row_end) dst[0] = v0;
-    } else {
-      if (gi0 < row_end) dst[0] = v0;
-      if (gi0 + 1 < row_end) dst[1] = v1;
+    if constexpr (!FUSE) return;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int64_t gj = tj + wave * 16 + c;
+      if (gj >= col_end) break;
+      double v0 = finish<KID>(s0[c], a.ks), v1 = finish<KID>(s1[c], a.ks);
+      if (MODE == PAD_IDENTITY) {
+        const bool jin = gj < a.nB;
+        v0 = (jin && gi0 < a.nA) ? v0 + (gi0 == gj ? a.noise : 0.0) : (gi0 == gj ? 1.0 : 0.0);
+        v1 = (jin && gi0 + 1 < a.nA) ? v1 + (gi0 + 1 == gj ? a.noise : 0.0) : (gi0 + 1 == gj ? 1.0 : 0.0);
+      } else if (MODE == PAD_ZERO) {
+        const bool jin = gj < a.nB;
+        v0 = (jin && gi0 < a.nA) ? v0 : 0.0;
+        v1 = (jin && gi0 + 1 < a.nA) ? v1 : 0.0;
+      }
+      if constexpr (FUSE) {  // identical arithmetic to the interior branch: a padding entry is an exact zero and adds nothing
+        if (a.w) { const double wj = a.w[gj]; m0 = fma(v0, wj, m0); m1 = fma(v1, wj, m1); }
+        if (a.colscale) { const double cs = a.colscale[gj]; v0 *= cs; v1 *= cs; }
+      }
+      double* dst = a.out + (gi0 - a.row0) + (gj - a.col0) * a.ld;
+      if constexpr (VEC2) {
+        if (gi0 + 1 < row_end) *reinterpret_cast<double2*>(dst) = make_double2(v0, v1);
+        else if (gi0 < row_end) dst[0] = v0;
+      } else {
+        if (gi0 < row_end) dst[0] = v0;
+        if (gi0 + 1 < row_end) dst[1] = v1;
+      }
+    }
+  }
+  if constexpr (FUSE) {
+    if (a.w) {  // the four waves' partials, summed in wave order
+      __syncthreads();  // everybody has left the accumulation loop: As is free
+      As[wave][2 * lane] = m0;
+      As[wave][2 * lane + 1] = m1;
+      __syncthreads();
+      if (t < FT_R) a.mpart[(int64_t)blockIdx.y * a.mpart_rows + (int64_t)blockIdx.x * FT_R + t] = ((As[0][t] + As[1][t]) + As[2][t]) + As[3][t];
     }
   }
 }
@@ -169,8 +200,16 @@ template <int KID, int MODE>
 int do_fill_mode(hipStream_t s, const FillArgs& a) {
   dim3 grid((unsigned)((a.nrows + FT_R - 1) / FT_R), (unsigned)((a.ncols + FT_C - 1) / FT_C));
   const bool vec2 = (a.ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
-  if (vec2) hipLaunchKernelGGL((fill_kernel<KID, true, MODE>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((fill_kernel<KID, false, MODE>), grid, dim3(256), 0, s, a);
+  if constexpr (MODE == PAD_ZERO) {
+    if (a.w || a.colscale) {
+      if (vec2) hipLaunchKernelGGL((fill_kernel<KID, true, MODE, true>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((fill_kernel<KID, false, MODE, true>), grid, dim3(256), 0, s, a);
+      GPRC_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  if (vec2) hipLaunchKernelGGL((fill_kernel<KID, true, MODE, false>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((fill_kernel<KID, false, MODE, false>), grid, dim3(256), 0, s, a);
   GPRC_LAUNCH_CHECK();
   return 0;
 }
@@ -250,14 +289,8 @@ __global__ __launch_bounds__(256) void set_identity_rows_kernel(double* vt, int6
 
 }  // namespace
 
-int launch_fill(hipStream_t s, const KernelSpec& ks, const double* A, int64_t nA, const double* B, int64_t nB, int64_t d,
-                double* out, int64_t ld, int64_t row0, int64_t nrows, int64_t col0, int64_t ncols, PadMode mode,
-                double noise) {
-  if (nrows <= 0 || ncols <= 0) return 0;
-  if ((ncols + FT_C - 1) / FT_C > 65535) { set_error("fill: too many column tiles in one launch"); return GPRC_ERR_ARG; }
-  FillArgs a{A, B, out, nA, nB, d, ld, row0, nrows, col0, ncols, (int)mode, noise, make_fill_spec(ks)};
-  ProfScope ps(s, PK_FILL, (double)nrows * ncols * (3.0 * d + 20.0), 8.0 * nrows * ncols);
-  switch (ks.id) {
+static int fill_dispatch(hipStream_t s, const FillArgs& a) {
+  switch (a.ks.id) {
     case GPRC_CONSTANT: return do_fill<GPRC_CONSTANT>(s, a);
     case GPRC_LINEAR: return do_fill<GPRC_LINEAR>(s, a);
     case GPRC_POLYNOMIAL: return do_fill<GPRC_POLYNOMIAL>(s, a);
@@ -266,6 +299,31 @@ int launch_fill(hipStream_t s, const KernelSpec& ks, const double* A, int64_t nA
     case GPRC_RATQUAD: return do_fill<GPRC_RATQUAD>(s, a);
     default: set_error("unknown kernel id"); return GPRC_ERR_ARG;
   }
+}
+
+int launch_fill(hipStream_t s, const KernelSpec& ks, const double* A, int64_t nA, const double* B, int64_t nB, int64_t d,
+                double* out, int64_t ld, int64_t row0, int64_t nrows, int64_t col0, int64_t ncols, PadMode mode,
+                double noise) {
+  if (nrows <= 0 || ncols <= 0) return 0;
+  if ((ncols + FT_C - 1) / FT_C > 65535) { set_error("fill: too many column tiles in one launch"); return GPRC_ERR_ARG; }
+  FillArgs a{A, B, out, nA, nB, d, ld, row0, nrows, col0, ncols, (int)mode, noise, make_fill_spec(ks), nullptr, nullptr, 0, nullptr};
+  ProfScope ps(s, PK_FILL, (double)nrows * ncols * (3.0 * d + 20.0), 8.0 * nrows * ncols);
+  return fill_dispatch(s, a);
+}
+
+int64_t fill_mean_tiles(int64_t cols) { return (cols + FT_C - 1) / FT_C; }
+
+// The predict's cross-covariance chunk with its fused epilogue: vt (m_pad x n_pad, zero padded) = K(X_star chunk, X)
+// [times colscale per column]; mpart[t * m_pad + i] = partial of (K*^T w)_i over column tile t (fill_mean_tiles(n_pad) tiles).
+int launch_fill_cross_fused(hipStream_t s, const KernelSpec& ks, const double* Xs, int64_t m, const double* X, int64_t n, int64_t d,
+                            double* vt, int64_t ld, int64_t m_pad, int64_t n_pad, const double* w, double* mpart, const double* colscale) {
+  if (m_pad <= 0 || n_pad <= 0) return 0;
+  if (m_pad % FT_R) { set_error("fill_cross_fused: m_pad must be a multiple of 128"); return GPRC_ERR_ARG; }
+  if (fill_mean_tiles(n_pad) > 65535) { set_error("fill: too many column tiles in one launch"); return GPRC_ERR_ARG; }
+  if (w && !mpart) { set_error("fill_cross_fused: partial buffer missing"); return GPRC_ERR_ARG; }
+  FillArgs a{Xs, X, vt, m, n, d, ld, 0, m_pad, 0, n_pad, (int)PAD_ZERO, 0.0, make_fill_spec(ks), w, mpart, m_pad, colscale};
+  ProfScope ps(s, PK_FILL, (double)m_pad * n_pad * (3.0 * d + 22.0), 8.0 * m_pad * n_pad);
+  return fill_dispatch(s, a);
 }
 
 int launch_colwise(hipStream_t s, const KernelSpec& ks, const double* x, const double* y, int64_t d, int64_t m, double* out) {

@@ -256,6 +256,16 @@ __global__ __launch_bounds__(256) void row_reduce_final(const double* part, int6
   out[row] = s;
 }
 
+// out[i] = sum_t part[t * stride + i] (minuend == nullptr) or minuend[i] - sum_t part[t * stride + i]; t ascending
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* part, int64_t nparts, int64_t stride, int64_t rows,
+                                                           const double* minuend, double* out) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  double s = 0.0;
+  for (int64_t t = 0; t < nparts; ++t) s += part[t * stride + row];
+  out[row] = minuend ? minuend[row] - s : s;
+}
+
 // ---- scalars -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void logp_kernel(const double* packed, int64_t n_pad, int64_t n, const double* y, const double* alpha,
                                                     double* out) {
@@ -445,6 +455,14 @@ int launch_row_reduce(hipStream_t s, const double* vt, int64_t ld, int64_t rows,
   ProfScope ps(s, PK_ROWREDUCE, 2.0 * rows * cols, 8.0 * rows * cols);
   hipLaunchKernelGGL(row_reduce_partial, dim3((unsigned)(rows / 128), (unsigned)splits), dim3(128), 0, s, vt, ld, cols, w, work, rows);
   hipLaunchKernelGGL(row_reduce_final, dim3(blocks(rows, 256)), dim3(256), 0, s, work, rows, (int)splits, out);
+  GPRC_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_sum_partials(hipStream_t s, const double* part, int64_t nparts, int64_t stride, int64_t rows, const double* minuend, double* out) {
+  if (rows <= 0) return 0;
+  ProfScope ps(s, PK_ROWREDUCE, (double)rows * nparts, 8.0 * rows * nparts);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks(rows, 256)), dim3(256), 0, s, part, nparts, stride, rows, minuend, out);
   GPRC_LAUNCH_CHECK();
   return 0;
 }
