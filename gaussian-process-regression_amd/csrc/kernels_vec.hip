@@ -6,6 +6,9 @@
 //   gpc_*           the elementwise IRLS stages                  R/GPCclass.R:78-86
 // All reductions use a fixed summation order (no floating-point atomics): results are bitwise
 // reproducible run to run.
+#include <cstdlib>
+#include <cstring>
+
 #include "gprc_internal.h"
 
 namespace gprc {
@@ -106,6 +109,21 @@ __global__ __launch_bounds__(1024) void trsv_diag_fwd(const double* packed, cons
   if (t < NB) bp[t] = z[t];
 }
 
+// One row's share of L[row, panel p columns] * x_p for column group g (NB/4 columns): four interleaved fma chains,
+// combined (s0 + s1) + (s2 + s3).  The per-panel step kernel and the single-launch flag kernel both call this, so the
+// two forms of the solve produce the same bits.
+__device__ __forceinline__ double gemv_group_partial(const double* Lr, int64_t ld, const double* xg) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+  for (int c = 0; c < NB / 4; c += 4) {
+    s0 = fma(Lr[(int64_t)c * ld], xg[c], s0);
+    s1 = fma(Lr[(int64_t)(c + 1) * ld], xg[c + 1], s1);
+    s2 = fma(Lr[(int64_t)(c + 2) * ld], xg[c + 2], s2);
+    s3 = fma(Lr[(int64_t)(c + 3) * ld], xg[c + 3], s3);
+  }
+  return (s0 + s1) + (s2 + s3);
+}
+
 // b[r] -= sum_c L[r, p*NB + c] * x_p[c] for the rows below panel p.  512 threads = 128 rows x 4 column groups.
 __global__ __launch_bounds__(512) void trsv_gemv_below(const double* packed, int64_t n_pad, int p, double* b) {
   __shared__ double xs[NB];
@@ -116,16 +134,7 @@ __global__ __launch_bounds__(512) void trsv_gemv_below(const double* packed, int
   const int64_t ld = panel_ld(n_pad, p);
   const int64_t row = (int64_t)(p + 1) * NB + (int64_t)blockIdx.x * 128 + i;
   const double* Lr = packed + panel_offset(n_pad, p) + (row - (int64_t)p * NB) + (int64_t)(g * (NB / 4)) * ld;
-  const double* xg = xs + g * (NB / 4);
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll 4
-  for (int c = 0; c < NB / 4; c += 4) {
-    s0 = fma(Lr[(int64_t)c * ld], xg[c], s0);
-    s1 = fma(Lr[(int64_t)(c + 1) * ld], xg[c + 1], s1);
-    s2 = fma(Lr[(int64_t)(c + 2) * ld], xg[c + 2], s2);
-    s3 = fma(Lr[(int64_t)(c + 3) * ld], xg[c + 3], s3);
-  }
-  red[g][i] = (s0 + s1) + (s2 + s3);
+  red[g][i] = gemv_group_partial(Lr, ld, xs + g * (NB / 4));
   __syncthreads();
   if (g == 0) b[row] -= (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
@@ -194,6 +203,15 @@ __global__ __launch_bounds__(1024) void trsv_diag_bwd(const double* packed, cons
   if (t < NB) xp[t] = z[t];
 }
 
+// One column's dot product with x_p over the NB rows of panel p (lanes stride the rows, fixed fma chain + wave tree):
+// shared by the per-panel step kernel and the flag kernel (same bits).
+__device__ __forceinline__ double gemvt_column_dot(const double* col, const double* xs, int lane) {
+  double s = 0.0;
+#pragma unroll
+  for (int r = 0; r < NB; r += 64) s = fma(col[r + lane], xs[r + lane], s);
+  return wave_sum(s);
+}
+
 // z[q*NB + c] -= sum_r L[p*NB + r, q*NB + c] * x_p[r] for every earlier panel q < p.  Block = (q, 32 columns).
 __global__ __launch_bounds__(256) void trsv_gemvt_above(const double* packed, int64_t n_pad, int p, double* z) {
   __shared__ double xs[NB];
@@ -206,13 +224,180 @@ __global__ __launch_bounds__(256) void trsv_gemvt_above(const double* packed, in
 #pragma unroll 2
   for (int k = 0; k < 8; ++k) {
     const int c = cg * 32 + w * 8 + k;
-    const double* col = blk + (int64_t)c * ld;
-    double s = 0.0;
-#pragma unroll
-    for (int r = 0; r < NB; r += 64) s = fma(col[r + lane], xs[r + lane], s);
-    s = wave_sum(s);
+    const double s = gemvt_column_dot(blk + (int64_t)c * ld, xs, lane);
     if (lane == 0) z[(int64_t)q * NB + c] -= s;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole solve in ONE launch (forward and backward): "sync-free" triangular solve over 256-row strips.
+//
+// The per-panel form above costs two launches per 512 columns, 2 x 128 dependent launches at n = 65536: 9 ms per solve,
+// all of it launch and drain latency.  Here every strip (half a panel) is a 1024-thread workgroup that
+//   * takes its strip number from a ticket counter (strip order = start order: a workgroup only ever waits for strips
+//     whose workgroups are already running -- no deadlock whatever the dispatch order or residency),
+//   * walks through the panels that precede it (forward) / follow it (backward), waiting on ONE monotone counter
+//     `done` (strips complete strictly in order) and subtracting each panel's contribution from its right-hand side
+//     with gemv_group_partial / gemvt_column_dot -- the SAME per-row / per-column arithmetic, in the same order, as
+//     the per-panel kernels, so both forms give identical bits (tests/test_gpu_device_level.py),
+//   * solves its half of the panel's diagonal block with the trsv_*_phase code of the per-panel form,
+//   * publishes its part of x and bumps `done`.
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): producer = plain stores, every storing wave's
+// s_waitcnt vmcnt(0), workgroup barrier, one lane's agent-scope release fence + vmcnt(0), relaxed agent-scope store of
+// the counter; consumer = one lane polls the counter with relaxed agent-scope loads (s_sleep between polls), agent-scope
+// acquire fence + vmcnt(0), workgroup barrier, plain loads.
+// While a strip waits for the panel right in front of it, it runs that panel's product once with whatever x is there
+// and throws the result away: the L block is then in this XCD's L2 when the real product is on the critical path.
+// ------------------------------------------------------------------------------------------------
+struct TrsvSync { int ticket; int done; int failed; int pad; };
+
+__device__ __forceinline__ void strip_wait(TrsvSync* sy, int need, int& seen, int* sh) {
+  if (seen >= need) return;                      // uniform over the workgroup: `seen` is the same in every thread
+  if (threadIdx.x == 0) {
+    int d, spins = 0;
+    while ((d = __hip_atomic_load(&sy->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+      __builtin_amdgcn_s_sleep(2);
+      // Exit condition every wave reaches: a predecessor that never publishes (a fault elsewhere) must not leave this
+      // workgroup spinning on the GPU for ever.  ~2^25 polls is tens of seconds -- far beyond any legitimate wait; the
+      // counter is then pushed past every strip so the whole grid drains (the solve's result is garbage and the
+      // `failed` word says so).
+      if (++spins > (1 << 25)) {
+        __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sy->done, 1 << 30, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        d = 1 << 30;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *sh = d;
+  }
+  __syncthreads();
+  seen = *sh;
+  __syncthreads();
+}
+
+__device__ __forceinline__ void strip_publish(TrsvSync* sy, int value) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores of x
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_max(&sy->done, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // max: never lowers a counter the bail-out pushed past the end
+  }
+}
+
+__global__ __launch_bounds__(1024) void trsv_fwd_flag_kernel(const double* packed, const double* winv, int64_t n_pad, double* b, TrsvSync* sy) {
+  __shared__ double z[NB];          // the panel's right-hand side / solution as the diagonal phases see it
+  __shared__ double zs[256];        // this strip's 256 entries while the earlier panels are being subtracted
+  __shared__ double xs[NB];         // x of the panel being applied
+  __shared__ double red[8][128];
+  __shared__ int sh;
+  static_assert(TPP == 4, "the flag solve is written for four 128-blocks per panel");
+  const int t = threadIdx.x;
+  if (t == 0) sh = atomicAdd(&sy->ticket, 1);
+  __syncthreads();
+  const int q = sh;                 // strip number: panel ps, half h
+  __syncthreads();
+  const int ps = q >> 1, h = q & 1;
+  const int64_t row0 = (int64_t)ps * NB + h * 256;
+  if (t < 256) zs[t] = b[row0 + t];
+  int seen = 0;
+  // rows of this strip: sub-strip (t >> 9), row i, column group g -- the thread layout of trsv_gemv_below, twice
+  const int sub = t >> 9, i = t & 127, g = (t >> 7) & 3;
+  const int64_t row = row0 + sub * 128 + i;
+  __syncthreads();
+  for (int p = 0; p < ps; ++p) {
+    const int64_t ld = panel_ld(n_pad, p);
+    const double* Lr = packed + panel_offset(n_pad, p) + (row - (int64_t)p * NB) + (int64_t)(g * (NB / 4)) * ld;
+    if (seen < 2 * p + 2) {         // will have to wait: warm this XCD's L2 with the block first (result discarded)
+      const double warm = gemv_group_partial(Lr, ld, xs + g * (NB / 4));
+      if (warm == 1.2345e-300) red[g + 4][i] = warm;   // never true in practice; keeps the loads alive
+      strip_wait(sy, 2 * p + 2, seen, &sh);
+    }
+    if (t < NB) xs[t] = b[(int64_t)p * NB + t];
+    __syncthreads();
+    red[sub * 4 + g][i] = gemv_group_partial(Lr, ld, xs + g * (NB / 4));
+    __syncthreads();
+    if (g == 0) zs[sub * 128 + i] -= (red[sub * 4][i] + red[sub * 4 + 1][i]) + (red[sub * 4 + 2][i] + red[sub * 4 + 3][i]);
+    __syncthreads();
+  }
+  // the diagonal block: phases 2h and 2h + 1 of trsv_diag_fwd; the second strip of a panel needs the first one's x
+  const int64_t ld = panel_ld(n_pad, ps);
+  const double* pan = packed + panel_offset(n_pad, ps);
+  const double* W = winv + (int64_t)ps * TPP * 128 * 128;
+  const int di = t & 127, ty = t >> 7;
+  if (h == 1) {
+    strip_wait(sy, q, seen, &sh);
+    if (t < 256) z[t] = b[(int64_t)ps * NB + t];
+  }
+  if (t < 256) z[h * 256 + t] = zs[t];
+  __syncthreads();
+  if (h == 0) {
+    trsv_fwd_phase<0>(pan, ld, W, z, red, di, ty);
+    trsv_fwd_phase<1>(pan, ld, W + 128 * 128, z, red, di, ty);
+  } else {
+    trsv_fwd_phase<2>(pan, ld, W + 2 * 128 * 128, z, red, di, ty);
+    trsv_fwd_phase<3>(pan, ld, W + 3 * 128 * 128, z, red, di, ty);
+  }
+  if (t < 256) b[row0 + t] = z[h * 256 + t];
+  strip_publish(sy, q + 1);
+}
+
+__global__ __launch_bounds__(1024) void trsv_bwd_flag_kernel(const double* packed, const double* winv, int64_t n_pad, double* x, TrsvSync* sy) {
+  __shared__ double z[NB];
+  __shared__ double zs[256];
+  __shared__ double xs[NB];
+  __shared__ double v[128];
+  __shared__ int sh;
+  const int P = (int)(n_pad / NB);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t == 0) sh = atomicAdd(&sy->ticket, 1);
+  __syncthreads();
+  const int q = sh;                 // completion order: the LAST strip of the matrix is q = 0
+  __syncthreads();
+  const int ps = P - 1 - (q >> 1), h = 1 - (q & 1);
+  const int64_t col0 = (int64_t)ps * NB + h * 256;
+  if (t < 256) zs[t] = x[col0 + t];
+  int seen = 0;
+  const int64_t ldq = panel_ld(n_pad, ps);
+  const double* mine = packed + panel_offset(n_pad, ps) + (int64_t)(h * 256) * ldq;   // column h*256 of my panel, row ps*NB
+  __syncthreads();
+  for (int p = P - 1; p > ps; --p) {          // panels behind me, in the order they complete
+    const double* blk = mine + (int64_t)(p - ps) * NB;   // rows of panel p
+    const int need = 2 * (P - p);
+    if (seen < need) {
+      double warm = 0.0;
+      for (int k = 0; k < 16; ++k) warm += gemvt_column_dot(blk + (int64_t)(w * 16 + k) * ldq, xs, lane);
+      if (warm == 1.2345e-300) v[lane] = warm;
+      strip_wait(sy, need, seen, &sh);
+    }
+    if (t < NB) xs[t] = x[(int64_t)p * NB + t];
+    __syncthreads();
+    for (int k = 0; k < 16; ++k) {             // wave w: columns w*16 .. w*16 + 15 of the strip
+      const int c = w * 16 + k;
+      const double s = gemvt_column_dot(blk + (int64_t)c * ldq, xs, lane);
+      if (lane == 0) zs[c] -= s;
+    }
+    __syncthreads();
+  }
+  const double* pan = packed + panel_offset(n_pad, ps);
+  const double* W = winv + (int64_t)ps * TPP * 128 * 128;
+  if (h == 0) {
+    strip_wait(sy, q, seen, &sh);
+    if (t < 256) z[256 + t] = x[(int64_t)ps * NB + 256 + t];
+  }
+  if (t < 256) z[h * 256 + t] = zs[t];
+  __syncthreads();
+  if (h == 1) {
+    trsv_bwd_phase<3>(pan, ldq, W + 3 * 128 * 128, z, v, lane, w);
+    trsv_bwd_phase<2>(pan, ldq, W + 2 * 128 * 128, z, v, lane, w);
+  } else {
+    trsv_bwd_phase<1>(pan, ldq, W + 128 * 128, z, v, lane, w);
+    trsv_bwd_phase<0>(pan, ldq, W, z, v, lane, w);
+  }
+  if (t < 256) x[col0 + t] = z[h * 256 + t];
+  strip_publish(sy, q + 1);
 }
 
 // ---- row reductions over a tall column-major matrix --------------------------------------------
@@ -435,10 +620,20 @@ int launch_trsv_step(hipStream_t s, const double* packed, const double* winv, in
   return 0;
 }
 
+// work: gprc_trsv_work_size(n_pad) doubles; its first bytes hold the ticket / progress counters of the flag kernels.
+// GPRC_TRSV=steps forces the per-panel launches (same bits).
 int launch_trsv(hipStream_t s, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose, double* work) {
-  (void)work;
   const int P = (int)(n_pad / NB);
   ProfScope ps(s, PK_TRSV, (double)n_pad * n_pad, 8.0 * 0.5 * n_pad * n_pad);
+  static const bool steps = [] { const char* e = std::getenv("GPRC_TRSV"); return e && std::strcmp(e, "steps") == 0; }();
+  if (!steps && work) {
+    TrsvSync* sy = reinterpret_cast<TrsvSync*>(work);
+    GPRC_HIP(hipMemsetAsync(sy, 0, sizeof(TrsvSync), s));
+    if (!transpose) hipLaunchKernelGGL(trsv_fwd_flag_kernel, dim3((unsigned)(2 * P)), dim3(1024), 0, s, packed, winv, n_pad, b, sy);
+    else hipLaunchKernelGGL(trsv_bwd_flag_kernel, dim3((unsigned)(2 * P)), dim3(1024), 0, s, packed, winv, n_pad, b, sy);
+    GPRC_LAUNCH_CHECK();
+    return 0;
+  }
   if (!transpose)
     for (int p = 0; p < P; ++p) GPRC_TRY(launch_trsv_step(s, packed, winv, n_pad, b, 0, p));
   else

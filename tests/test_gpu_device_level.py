@@ -76,8 +76,12 @@ def test_sweep_variants_are_bit_identical():
     ctx.close()
 
 
-def test_solve_in_panel_steps_is_bit_identical():
-    n = 2100
+@pytest.mark.parametrize("n,reps", [(2100, 1), (9100, 4)])
+def test_solve_in_panel_steps_is_bit_identical(n, reps):
+    """gprc_dev_trsv is ONE launch per solve: 256-row strips that hand x over through an agent-scope progress counter
+    (trsv_*_flag_kernel); gprc_dev_trsv_step is the per-panel form the multi-rank sweep runs beside the factorisation.
+    Same per-row / per-column arithmetic in the same order, so every word must be equal -- which is also the check that
+    no strip ever read a stale x (repeated: the hand-off is exercised with warm caches and varying arrival order)."""
     L, ctx, g, a = _filled(n, seed=32)
     w, info = _new(g)
     nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr()))
@@ -85,13 +89,15 @@ def test_solve_in_panel_steps_is_bit_identical():
     b0 = torch.from_numpy(np.concatenate([rng.normal(size=n), np.zeros(g.n_pad - n)])).cuda()
     work = torch.zeros(g.trsv_work, dtype=torch.float64, device="cuda")
     for transpose in (0, 1):
-        whole, steps = b0.clone(), b0.clone()
-        nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, whole.data_ptr(), transpose, work.data_ptr()))
+        steps = b0.clone()
         order = range(g.P) if not transpose else range(g.P - 1, -1, -1)
         for p in order:
             nat.check(L.gprc_dev_trsv_step(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, steps.data_ptr(), transpose, p))
-        torch.cuda.synchronize()
-        assert torch.equal(whole, steps)
+        for _ in range(reps):
+            whole = b0.clone()
+            nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, whole.data_ptr(), transpose, work.data_ptr()))
+            torch.cuda.synchronize()
+            assert torch.equal(whole, steps)
     # and it is a solve: L (L^T x) = b
     x = b0.clone()
     nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, x.data_ptr(), 0, work.data_ptr()))
