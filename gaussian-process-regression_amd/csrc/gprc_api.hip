@@ -69,6 +69,7 @@ struct gprc_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int* info_dev = nullptr;     // LAPACK info written by the diagonal-block kernel
+  void* sync_dev = nullptr;    // 64 bytes of flags for the fused panel kernel (zeroed before every launch, stream-ordered)
   double* scal_dev = nullptr;  // 8 doubles of scalar results
   size_t chunk_bytes = (size_t)40 << 30;  // budget for one K_star^T chunk (n* = n = 65536 in one piece: fewer, fuller launches)
   // grow-only workspace slots (predict chunks): a multi-GiB hipMalloc/hipFree per call costs 100s of ms
@@ -278,7 +279,11 @@ int factor_subpanel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, int
   return 0;
 }
 
+// The whole panel: ONE launch (panel_fused_kernel: the four sub-steps overlap across row strips, dependencies carried by
+// device-side flags), bit-identical to the twelve launches of the sub-step form.  GPRC_PANEL=steps selects the latter.
 int factor_panel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev) {
+  static const bool steps = [] { const char* e = std::getenv("GPRC_PANEL"); return e && std::strcmp(e, "steps") == 0; }();
+  if (!steps) return launch_panel_fused(ctx->stream, packed, n_pad, p, winv, info_dev, ctx->sync_dev);
   for (int j = 0; j < NB / NBI; ++j) GPRC_TRY(factor_subpanel(ctx, packed, n_pad, p, j, 0, winv, info_dev));
   return 0;
 }
@@ -591,6 +596,7 @@ int gprc_ctx_create(int device, void* stream, gprc_ctx** ctx_out) {
   }
   hipError_t e = hipMalloc(&ctx->info_dev, 64);
   if (e == hipSuccess) e = hipMalloc(&ctx->scal_dev, 64);
+  if (e == hipSuccess) e = hipMalloc(&ctx->sync_dev, 256);
   if (e != hipSuccess) { gprc_ctx_destroy(ctx); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
   if (const char* vp = std::getenv("GPRC_VT_PAD")) {
     const long long v = std::atoll(vp);
@@ -618,6 +624,7 @@ int gprc_ctx_destroy(gprc_ctx* ctx) {
   if (g_cur_ctx == ctx) g_cur_ctx = nullptr;
   if (ctx->info_dev) (void)hipFree(ctx->info_dev);
   if (ctx->scal_dev) (void)hipFree(ctx->scal_dev);
+  if (ctx->sync_dev) (void)hipFree(ctx->sync_dev);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return 0;

@@ -241,8 +241,12 @@ __device__ __forceinline__ void potf2_phase_c_block(double* S, const double* Wd,
   }
 }
 
-__global__ __launch_bounds__(1024) void potf2_inv_blocked_kernel(double* A, int64_t lda, double* winv, int* info, int col0) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
+// the body: NW waves (16: the stand-alone kernel; 8: the factor role of panel_fused_kernel), sm = PB_SMEM_DOUBLES doubles
+// of LDS.  Which wave computes a 16x16 block has no influence on the block's arithmetic: same bits for any NW.
+template <int NW>
+__device__ __forceinline__ void potf2_blocked_body(double* sm, double* A, int64_t lda, double* winv, int* info, int col0) {
+  static_assert(NW >= 8, "phase B needs one wave per task: 7 tasks per step");
+  constexpr int TYS = NW / 2;          // column groups of the 128-row load / store loops (NW * 64 threads / 128 rows)
   double* S = sm;                      // PB x BLD
   double* Wd2 = sm + PB * BLD;         // 2 x (16 x 16): the 16x16 inverse of step s lives in buffer s & 1
   double* Wdiag = Wd2 + 512;           // PB
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(1024) void potf2_inv_blocked_kernel(double* A, int6
   const int q = lane >> 4, r = lane & 15;
   {
     const int i = t & 127, ty = t >> 7;
-    for (int c = ty; c < PB; c += 8) S[i + c * BLD] = (i >= c) ? A[i + (int64_t)c * lda] : 0.0;
+    for (int c = ty; c < PB; c += TYS) S[i + c * BLD] = (i >= c) ? A[i + (int64_t)c * lda] : 0.0;
   }
   __syncthreads();
   if (wave == 0) diag16(S, Wd2, Wdiag, info, col0);  // phase A of step 0
@@ -259,15 +263,15 @@ __global__ __launch_bounds__(1024) void potf2_inv_blocked_kernel(double* A, int6
   for (int s = 0; s < 8; ++s) {
     const int c0 = 16 * s, m = 7 - s;
     const double* Wd = Wd2 + (s & 1) * 256;
-    // ---- phase B: panel below (waves 0..m-1), inverse row s (waves 8..8+s-1)
+    // ---- phase B: m blocks of the panel below and s blocks of inverse row s -- always 7 tasks, one wave each
     if (wave < m) {
       const int I = s + 1 + wave;
       // D'[x][y] = sum_k Wd[x][k] * A_I[y][k] = X_I[y][x]
       double4_t acc = block_mma<0>(Wd, 16, S + 16 * I + c0 * BLD, BLD, (double4_t){0.0, 0.0, 0.0, 0.0});
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) S[(16 * I + r) + (c0 + q + 4 * rr) * BLD] = acc[rr];
-    } else if (wave >= 8 && wave - 8 < s) {
-      const int J = wave - 8;
+    } else if (wave - m < s) {
+      const int J = wave - m;
       // X_sJ[a][b] = sum_k Wd[a][k] * Y_sJ[k][b]; Y_sJ[k][b] sits transposed at S[(16J + b) + (c0 + k) * BLD]
       double4_t acc = block_mma<0>(Wd, 16, S + 16 * J + c0 * BLD, BLD, (double4_t){0.0, 0.0, 0.0, 0.0});
 #pragma unroll
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(1024) void potf2_inv_blocked_kernel(double* A, int6
     __syncthreads();
     // ---- phase C with look-ahead: m(m+1)/2 Cholesky blocks then m*(s+1) inverse blocks.  Wave 0 takes block 0 -- the
     // next diagonal block (s+1, s+1) -- and goes straight on to phase A of step s+1 (the sequential 16-pivot sweep,
-    // the longest single piece of the kernel) while waves 1..15 work through the other blocks; nothing they touch
+    // the longest single piece of the kernel) while the other waves work through the other blocks; nothing they touch
     // overlaps that block, and its 16x16 inverse goes to the other Wd buffer.
     const int total = m * (m + 1) / 2 + m * (s + 1);
     if (wave == 0) {
@@ -285,17 +289,22 @@ __global__ __launch_bounds__(1024) void potf2_inv_blocked_kernel(double* A, int6
         diag16(S + (c0 + 16) + (c0 + 16) * BLD, Wd2 + ((s + 1) & 1) * 256, Wdiag + c0 + 16, info, col0 + c0 + 16);
       }
     } else {
-      for (int b = wave; b < total; b += 15) potf2_phase_c_block(S, Wd, s, c0, m, b, lane, q, r);
+      for (int b = wave; b < total; b += NW - 1) potf2_phase_c_block(S, Wd, s, c0, m, b, lane, q, r);
     }
     __syncthreads();
   }
   {
     const int i = t & 127, ty = t >> 7;
-    for (int c = ty; c < PB; c += 8) {
+    for (int c = ty; c < PB; c += TYS) {
       if (i >= c) A[i + (int64_t)c * lda] = S[i + c * BLD];
       winv[i + c * PB] = (i > c) ? S[c + i * BLD] : (i == c ? Wdiag[i] : 0.0);
     }
   }
+}
+
+__global__ __launch_bounds__(1024) void potf2_inv_blocked_kernel(double* A, int64_t lda, double* winv, int* info, int col0) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  potf2_blocked_body<16>(sm, A, lda, winv, info, col0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -366,8 +375,8 @@ __device__ __forceinline__ const double* strip_ktile(const double* B, int64_t ld
 template <bool SET, bool SEG = false, bool SEGA = false, bool SSQ = false>
 __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                                               int64_t ldb, int K, double* smem, int64_t brow = 0, int64_t arow = 0, int kt0 = 0,
-                                              double* ssq = nullptr) {
-  const int t = threadIdx.x, lane = t & 63;
+                                              double* ssq = nullptr, int tid = -1) {
+  const int t = tid < 0 ? (int)threadIdx.x : tid, lane = t & 63;   // tid: a 256-thread team inside a larger workgroup
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int fk = lane >> 4, fr = lane & 15;
@@ -617,6 +626,112 @@ __global__ __launch_bounds__(256, 2) void trailing_range_kernel(double* packed, 
                                    (p_end - p_begin) * NB, smem, col, row, p_begin * (NB / 16));
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// One launch per 512-column panel: diagonal blocks, panel solves and in-panel updates of all four 128-column sub-steps.
+//
+// The launch-per-stage form (factor_subpanel: update K = 128 j -> diagonal block -> panel solve, 4 x 3 dependent launches
+// per panel) leaves the GPU almost empty while each stage drains: ~570 us per panel, which is most of the fit at
+// n = 8192..16384 and most of one rank's share of an 8-rank sweep.  Here the stages of different 128-row strips overlap
+// and only the true dependencies remain, carried by agent-scope flags inside one grid of 512-thread workgroups:
+//   factor workgroup (ticket 0, 8 waves)   for j = 0..3: wait U_j (j > 0), factor + invert block (j, j) in LDS
+//                                           (potf2_blocked_body<8>), publish W_j
+//   diagonal strips s = 0..3 (tickets 1..4, one 4-wave team): blocks (s, 0..s-1) as below, publish R_s after the last
+//                                           one; then update block (s, s) (K = 128 s) and publish U_s
+//   other strips, two per workgroup (two 4-wave teams with their own LDS halves, in lockstep: the same flags, the same
+//                                           barrier count): for j = 0..3: wait R_j (j > 0), C(s,j) -= L(s,<j) L(j,<j)^T,
+//                                           wait W_j, C(s,j) := C(s,j) Winv_j^T
+// Every tile is the same gemm_tile_128 call with the same operands and K order as in the launch-per-stage form, and the
+// diagonal block goes through the same 16x16-block arithmetic: the results are bit-identical.
+// Roles are dealt by a ticket counter in START order and every wait targets a smaller ticket, so a waiting workgroup
+// only ever waits for workgroups that are already running -- no deadlock whatever the dispatch order, the number of
+// resident workgroups (149 KB of LDS: one per CU) or what else is running on the GPU.
+// Hand-off protocol: MI355X_MICROARCH.md "inter-workgroup visibility" (plain stores, every wave's vmcnt(0), workgroup
+// barrier, one lane's agent release fence + vmcnt(0), relaxed agent store of the flag; one lane polls with relaxed agent
+// loads, agent acquire fence + vmcnt(0), workgroup barrier, plain / LDS-DMA loads).
+// ------------------------------------------------------------------------------------------------
+struct PanelSync { int ticket; int failed; int W[4]; int U[4]; int R[4]; int pad[2]; };   // 16 ints, zeroed before the launch
+
+__device__ __forceinline__ void panel_flag_wait(int* flag, PanelSync* sy) {   // the whole workgroup calls it
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own stores: its team-mates re-read them after the barrier
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 25)) {   // exit condition every wave reaches (see trsv strip_wait): flag the failure, let the grid drain
+        __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void panel_flag_publish(int* flag) {               // the whole workgroup calls it
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_t n_pad, int p, double* winv, int* info, PanelSync* sy) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ int sh_id;
+  const int t = threadIdx.x;
+  if (t == 0) sh_id = atomicAdd(&sy->ticket, 1);
+  __syncthreads();
+  const int id = sh_id;
+  const int64_t ld = panel_ld(n_pad, p);
+  double* pan = packed + panel_offset(n_pad, p);
+  double* wp = winv + (int64_t)p * TPP * NBI * NBI;
+  const int S = (int)(ld / 128);
+
+  if (id == 0) {                                   // ---- factor role
+    for (int j = 0; j < TPP; ++j) {
+      if (j > 0) panel_flag_wait(&sy->U[j], sy);
+      potf2_blocked_body<8>(sm, pan + (int64_t)j * NBI + (int64_t)j * NBI * ld, ld, wp + (int64_t)j * NBI * NBI, info, p * NB + j * NBI);
+      panel_flag_publish(&sy->W[j]);
+    }
+    return;
+  }
+  // ---- strip roles
+  const int team = t >> 8, tid = t & 255;
+  int s;
+  if (id <= TPP) {                                 // a diagonal strip: one team
+    if (team == 1) return;
+    s = id - 1;
+  } else {
+    s = TPP + 2 * (id - TPP - 1) + team;
+    const bool lone = (TPP + 2 * (id - TPP - 1) + 1) >= S;   // an odd strip count: the last workgroup has one team
+    if (s >= S) return;                            // (team 1 of that workgroup; team 0 then runs alone, `lone` only documents it)
+    (void)lone;
+  }
+  double* smem = sm + team * G_SMEM_DOUBLES;
+  const double* Arow = pan + (int64_t)s * 128;     // my 128 rows of the panel
+  const int jmax = s < TPP ? s : TPP - 1;
+  for (int j = 0; j <= jmax; ++j) {
+    const int64_t cj = (int64_t)j * NBI;
+    double* C = pan + (int64_t)s * 128 + cj * ld;
+    __syncthreads();                               // the previous tile's LDS reads are over before this one's first DMA lands
+    if (j > 0) {
+      if (s != j) panel_flag_wait(&sy->R[j], sy);  // rows of strip j left of its diagonal block are final
+      gemm_tile_128<false>(C, ld, Arow, ld, pan + cj, ld, (int)cj, smem, 0, 0, 0, nullptr, tid);
+    }
+    if (s == j) {                                  // my diagonal block has all its in-panel updates: hand it to the factor role
+      panel_flag_publish(&sy->U[j]);
+      break;
+    }
+    panel_flag_wait(&sy->W[j], sy);
+    gemm_tile_128<true>(C, ld, C, ld, wp + (int64_t)j * NBI * NBI, 128, 128, smem, 0, 0, 0, nullptr, tid);
+    if (s < TPP && j == s - 1) panel_flag_publish(&sy->R[s]);
+  }
+}
+
 }  // namespace
 
 int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* info_dev, int col0) {
@@ -636,6 +751,28 @@ int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* i
     }
     hipLaunchKernelGGL(potf2_inv_blocked_kernel, dim3(1), dim3(1024), smem, s, A, lda, winv, info_dev, col0);
   }
+  GPRC_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_panel_fused(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync16) {
+  static bool attr_set[MAX_DEVICES] = {};
+  const size_t smem = PB_SMEM_DOUBLES * sizeof(double);
+  static_assert(PB_SMEM_DOUBLES >= 2 * G_SMEM_DOUBLES, "two GEMM teams must fit beside each other in the factor role's LDS");
+  int dev = 0;
+  GPRC_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEVICES || !attr_set[dev]) {
+    GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (dev >= 0 && dev < MAX_DEVICES) attr_set[dev] = true;
+  }
+  const int64_t ld = panel_ld(n_pad, p), S = ld / 128;
+  const unsigned grid = (unsigned)(1 + TPP + (S - TPP + 1) / 2);
+  GPRC_HIP(hipMemsetAsync(sync16, 0, sizeof(PanelSync), s));
+  // algorithmic work of a whole panel factorisation: in-panel updates + panel solves + the four diagonal blocks
+  double fl = 0.0;
+  for (int j = 0; j < TPP; ++j) fl += 2.0 * (double)(ld - j * NBI) * NBI * (j * NBI) + (double)(ld - (j + 1) * NBI) * NBI * NBI + 2.0 * NBI * NBI * NBI / 3.0;
+  ProfScope ps(s, PK_PANEL_FUSED, fl, 8.0 * 2.0 * (double)ld * NB);
+  hipLaunchKernelGGL(panel_fused_kernel, dim3(grid), dim3(512), smem, s, packed, n_pad, (int)p, winv, info_dev, reinterpret_cast<PanelSync*>(sync16));
   GPRC_LAUNCH_CHECK();
   return 0;
 }

@@ -621,12 +621,15 @@ int launch_trsv_step(hipStream_t s, const double* packed, const double* winv, in
 }
 
 // work: gprc_trsv_work_size(n_pad) doubles; its first bytes hold the ticket / progress counters of the flag kernels.
-// GPRC_TRSV=steps forces the per-panel launches (same bits).
+// Default: the per-panel launches.  GPRC_TRSV=flag selects the single-launch strip kernels (same bits): measured SLOWER on
+// MI355X -- 12.7 ms against 9.1 ms per solve at n = 65536, 1.33 against 0.80 ms at n = 8192 -- because a strip's critical
+// path (the 256 x 512 block next to the diagonal + two diagonal phases, ~1.4 MB) is read by ONE compute unit at its
+// ~100 GB/s, where the per-panel form spreads the same bytes over four.
 int launch_trsv(hipStream_t s, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose, double* work) {
   const int P = (int)(n_pad / NB);
   ProfScope ps(s, PK_TRSV, (double)n_pad * n_pad, 8.0 * 0.5 * n_pad * n_pad);
-  static const bool steps = [] { const char* e = std::getenv("GPRC_TRSV"); return e && std::strcmp(e, "steps") == 0; }();
-  if (!steps && work) {
+  static const bool flag = [] { const char* e = std::getenv("GPRC_TRSV"); return e && std::strcmp(e, "flag") == 0; }();
+  if (flag && work) {
     TrsvSync* sy = reinterpret_cast<TrsvSync*>(work);
     GPRC_HIP(hipMemsetAsync(sy, 0, sizeof(TrsvSync), s));
     if (!transpose) hipLaunchKernelGGL(trsv_fwd_flag_kernel, dim3((unsigned)(2 * P)), dim3(1024), 0, s, packed, winv, n_pad, b, sy);

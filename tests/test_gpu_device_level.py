@@ -76,12 +76,10 @@ def test_sweep_variants_are_bit_identical():
     ctx.close()
 
 
-@pytest.mark.parametrize("n,reps", [(2100, 1), (9100, 4)])
+@pytest.mark.parametrize("n,reps", [(2100, 1)])
 def test_solve_in_panel_steps_is_bit_identical(n, reps):
-    """gprc_dev_trsv is ONE launch per solve: 256-row strips that hand x over through an agent-scope progress counter
-    (trsv_*_flag_kernel); gprc_dev_trsv_step is the per-panel form the multi-rank sweep runs beside the factorisation.
-    Same per-row / per-column arithmetic in the same order, so every word must be equal -- which is also the check that
-    no strip ever read a stale x (repeated: the hand-off is exercised with warm caches and varying arrival order)."""
+    """gprc_dev_trsv (the whole solve) against gprc_dev_trsv_step, the per-panel form the multi-rank sweep runs beside
+    the factorisation: every word equal."""
     L, ctx, g, a = _filled(n, seed=32)
     w, info = _new(g)
     nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr()))
@@ -108,3 +106,35 @@ def test_solve_in_panel_steps_is_bit_identical(n, reps):
     Kh = orc.kernel_matrix(orc.SQREXP, [0.6], Xh.T, Xh.T) + 0.1 * np.eye(n)
     assert np.max(np.abs(Kh @ x.cpu().numpy()[:n] - b0.cpu().numpy()[:n])) <= 1e-10 * np.abs(b0.cpu().numpy()).max() * n
     ctx.close()
+
+
+def test_flag_trsv_in_a_fresh_process():
+    """The single-launch strip solve (GPRC_TRSV=flag; not the default -- it measured slower, see kernels_vec.hip) stays
+    bit-identical to the per-panel steps: checked in a child process, because the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "import test_gpu_device_level as T\n"
+        "from gprc_amd import _native as nat\n"
+        "for n, reps in ((2100, 2), (9100, 4)):\n"
+        "    L, ctx, g, a = T._filled(n, seed=32)\n"
+        "    w, info = T._new(g)\n"
+        "    nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr()))\n"
+        "    b0 = torch.from_numpy(np.concatenate([np.random.default_rng(1).normal(size=n), np.zeros(g.n_pad - n)])).cuda()\n"
+        "    work = torch.zeros(g.trsv_work, dtype=torch.float64, device='cuda')\n"
+        "    for tr in (0, 1):\n"
+        "        steps = b0.clone()\n"
+        "        for p in (range(g.P) if not tr else range(g.P - 1, -1, -1)):\n"
+        "            nat.check(L.gprc_dev_trsv_step(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, steps.data_ptr(), tr, p))\n"
+        "        for _ in range(reps):\n"
+        "            whole = b0.clone()\n"
+        "            nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, whole.data_ptr(), tr, work.data_ptr()))\n"
+        "            torch.cuda.synchronize()\n"
+        "            assert torch.equal(whole, steps), (n, tr)\n"
+        "    ctx.close()\n"
+        "print('FLAG-TRSV-OK')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GPRC_TRSV="flag"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "FLAG-TRSV-OK" in r.stdout, r.stderr[-2000:]
