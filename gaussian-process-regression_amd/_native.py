@@ -96,6 +96,18 @@ PROTOTYPES = {
     "gprc_dev_logp": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "gprc_gpr_model_from_device": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, _vp, _vp, _vp, C.c_double,
                                              C.c_double, C.POINTER(_vp)]),
+    "gprc_mgpu_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(_vp)]),
+    "gprc_mgpu_destroy": (C.c_int, [_vp]),
+    "gprc_mgpu_ranks": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "gprc_mgpu_gpr_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, C.c_double, C.POINTER(_vp)]),
+    "gprc_mgpu_gpr_fit_retry": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, C.c_double, C.POINTER(_vp),
+                                          C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "gprc_mgpu_gpr_predict": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "gprc_mgpu_gpr_get_alpha": (C.c_int, [_vp, _vp]),
+    "gprc_mgpu_gpr_get_logp": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "gprc_mgpu_gpr_get_noise": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "gprc_mgpu_model_rank": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "gprc_mgpu_model_free": (C.c_int, [_vp]),
     "gprc_mvn_factor": (C.c_int, [_vp, _vp, _i64, _i64, C.c_double, _vp, C.POINTER(C.c_int)]),
     "gprc_mvn_sample": (C.c_int, [_vp, _vp, _i64, _i64, _vp, C.c_double, _vp, _i64, _vp, C.POINTER(C.c_int)]),
     "gprc_sym_eigen": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, C.POINTER(C.c_int)]),

@@ -11,10 +11,10 @@ NBW="${GPRC_NB:-512}"
 SUFFIX="${GPRC_LIB_SUFFIX:-}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form=1 -Wall -Wno-unused-function -DGPRC_NB="$NBW" ${GPRC_EXTRA_FLAGS:-})
 objs=()
-for src in gprc_api kernels_fill kernels_chol kernels_vec kernels_eig; do
+for src in gprc_api gprc_mgpu kernels_fill kernels_chol kernels_vec kernels_eig; do
   "$HIPCC" "${FLAGS[@]}" -c "$here/$src.hip" -o "$out/$src$SUFFIX.o" &
   objs+=("$out/$src$SUFFIX.o")
 done
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libgprc_native$SUFFIX.so" "${objs[@]}"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libgprc_native$SUFFIX.so" "${objs[@]}" -ldl -lpthread
 echo "built $out/libgprc_native$SUFFIX.so"

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <utility>
 #include <vector>
@@ -42,13 +43,16 @@ hipEvent_t prof_event() {
   return e;
 }
 }  // namespace
+std::mutex g_prof_mu;  // gprc_mgpu_gpr_predict runs one host thread per rank
 bool prof_enabled() { return g_prof_on; }
 void prof_begin(hipStream_t s, int kind) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r{kind, 0.0, 0.0, prof_event(), nullptr};
   (void)hipEventRecord(r.e0, s);
   g_prof_open.push_back(r);
 }
 void prof_end(hipStream_t s, int kind, double flops, double bytes) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (size_t i = g_prof_open.size(); i-- > 0;) {
     if (g_prof_open[i].kind != kind) continue;
     ProfRec r = g_prof_open[i];
@@ -70,6 +74,11 @@ struct gprc_ctx {
   bool own_stream = false;
   int* info_dev = nullptr;     // LAPACK info written by the diagonal-block kernel
   void* sync_dev = nullptr;    // 64 bytes of flags for the fused panel kernel (zeroed before every launch, stream-ordered)
+                               // + another 64 for launches on the look-ahead stream
+  // one-GPU look-ahead (factor_all_async): the panel chain runs on a high-priority side stream beside the trailing update
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned ev_next = 0;
   double* scal_dev = nullptr;  // 8 doubles of scalar results
   size_t chunk_bytes = (size_t)40 << 30;  // budget for one K_star^T chunk (n* = n = 65536 in one piece: fewer, fuller launches)
   // grow-only workspace slots (predict chunks): a multi-GiB hipMalloc/hipFree per call costs 100s of ms
@@ -296,6 +305,43 @@ int factor_panel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, double
 // so a pass needs many generations of tiles per CU or the partially filled last one costs more than the saved
 // prologues (measured at n = 32768 / 65536: 1024 tiles -6 %, 8192 tiles +3 % / +7 % on the fit against right-looking).
 // GPRC_FACTOR=right: one group = right-looking; GPRC_FACTOR=<tiles> changes the threshold.
+// `to` waits for everything enqueued on `from` so far (events recycled round-robin: a wait captures the record made here)
+int stream_after(gprc_ctx* ctx, hipStream_t to, hipStream_t from) {
+  hipEvent_t& ev = ctx->ev_pool[ctx->ev_next++ % 8];
+  if (!ev) GPRC_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  GPRC_HIP(hipEventRecord(ev, from));
+  GPRC_HIP(hipStreamWaitEvent(to, ev, 0));
+  return 0;
+}
+
+// Right-looking sweep with LOOK-AHEAD on one GPU: the chain that factors panel p + 1 (one fused launch: a handful of
+// latency-bound workgroups) runs on a high-priority side stream while the main stream is still applying panel p to the
+// panels behind p + 1.  Same launches on the same data as the plain right-looking sweep -- only their overlap differs --
+// so the factor is bit-identical.  It pays where the chain is a large share of the fit (n <= ~16k: at n = 8192 the chain
+// is 6.6 of 12.3 ms, at n = 16384 14 of 44 ms per Cholesky); beyond that the grouped left-looking schedule below wins.
+int factor_all_lookahead(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev) {
+  hipStream_t s = ctx->stream;
+  const int64_t P = n_pad / NB;
+  if (!ctx->side_stream) {
+    int lo = 0, hi = 0;
+    GPRC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    GPRC_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi));
+  }
+  hipStream_t side = ctx->side_stream;
+  void* sync_side = static_cast<char*>(ctx->sync_dev) + 64;
+  GPRC_TRY(stream_after(ctx, side, s));                       // the fill (and the caller's memset of info) precede the chain
+  GPRC_TRY(launch_panel_fused(side, packed, n_pad, 0, winv, info_dev, sync_side));
+  for (int64_t p = 0; p + 1 < P; ++p) {
+    GPRC_TRY(stream_after(ctx, s, side));                     // panel p is factored
+    GPRC_TRY(launch_trailing_update(s, packed, n_pad, p, p + 1, p + 2, 1));        // panel p + 1 first ...
+    GPRC_TRY(stream_after(ctx, side, s));
+    GPRC_TRY(launch_panel_fused(side, packed, n_pad, p + 1, winv, info_dev, sync_side));   // ... its chain on the side stream
+    if (p + 2 < P) GPRC_TRY(launch_trailing_update(s, packed, n_pad, p, p + 2, P, 1));     // ... beside the rest of update p
+  }
+  GPRC_TRY(stream_after(ctx, s, side));
+  return 0;
+}
+
 int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev) {
   hipStream_t s = ctx->stream;
   const int64_t P = n_pad / NB;
@@ -303,6 +349,10 @@ int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv,
   int64_t want = 8192;
   if (mode && std::strcmp(mode, "right") == 0) want = INT64_MAX;
   else if (mode && std::atoll(mode) > 0) want = std::atoll(mode);
+  // GPRC_LOOKAHEAD1=0/1 forces the choice; default: look-ahead up to n_pad = 24576
+  static const int la_env = [] { const char* e = std::getenv("GPRC_LOOKAHEAD1"); return e ? std::atoi(e) : -1; }();
+  static const bool panel_steps = [] { const char* e = std::getenv("GPRC_PANEL"); return e && std::strcmp(e, "steps") == 0; }();
+  if (!mode && !panel_steps && P >= 2 && (la_env == 1 || (la_env < 0 && n_pad <= 24576))) return factor_all_lookahead(ctx, packed, n_pad, winv, info_dev);
   for (int64_t g0 = 0; g0 < P;) {
     int64_t g1 = g0, tiles = 0;
     while (g1 < P && tiles < want) { tiles += (int64_t)TPP * TPP * (P - g1) - TPP * (TPP - 1) / 2; ++g1; }
@@ -625,6 +675,9 @@ int gprc_ctx_destroy(gprc_ctx* ctx) {
   if (ctx->info_dev) (void)hipFree(ctx->info_dev);
   if (ctx->scal_dev) (void)hipFree(ctx->scal_dev);
   if (ctx->sync_dev) (void)hipFree(ctx->sync_dev);
+  if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+  for (hipEvent_t ev : ctx->ev_pool)
+    if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return 0;

@@ -229,6 +229,44 @@ GPRC_API int gprc_gpr_model_from_device(gprc_ctx* ctx, int kernel, const double*
 GPRC_API int gprc_dev_solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt,
                         int64_t ld, int64_t m_pad);
 
+/* ---- multi-GPU from ONE process (SURVEY 8b "Threading", 8e): the form the R `.Call` boundary can use ------------ *
+ * The reference's host is a single R process; it cannot be forked per GPU.  A gprc_mgpu drives G ranks -- one per
+ * listed device, each with its own streams and buffers -- from the calling thread and runs the SAME sweep as the
+ * one-process-per-GPU driver: panel p of the packed factor is owned by rank p mod G (1-D block-cyclic), the owner
+ * factors it on a side stream beside the trailing update of the previous panel (look-ahead), every rank receives every
+ * panel -- the ONE exchange step -- so L ends up replicated, alpha is solved on every rank, and the test points of a
+ * predict are sliced over the ranks with no exchange.  Replaces GPR$initialize / GPR$predict (R/GPRclass.R:127-170)
+ * exactly as gprc_gpr_fit / gprc_gpr_predict do, with bit-identical results.
+ *   devices  n_ranks device indices.  A device may be listed SEVERAL times: "virtual ranks" that share a GPU and
+ *            exchange panels by device-to-device copies -- how a one-GPU box exercises the G = 2, 3 sweeps.
+ *   flags    GPRC_MGPU_RCCL: the exchange is ncclBroadcast over xGMI (single-process ncclCommInitAll + group calls;
+ *            distinct devices only; librccl.so.1 is resolved at run time).  0: peer copies (hipMemcpyPeerAsync).
+ *            GPRC_MGPU_NO_LOOKAHEAD: factor panel p+1 only after the whole trailing update of panel p.
+ * All data pointers of these calls are HOST memory (REAL(x) of the `.Call` case). */
+#define GPRC_MGPU_RCCL 1
+#define GPRC_MGPU_NO_LOOKAHEAD 2
+typedef struct gprc_mgpu gprc_mgpu;
+typedef struct gprc_mgpu_model gprc_mgpu_model;
+GPRC_API int gprc_mgpu_create(const int* devices, int n_ranks, int flags, gprc_mgpu** mgpu_out);
+GPRC_API int gprc_mgpu_destroy(gprc_mgpu* mgpu);
+GPRC_API int gprc_mgpu_ranks(const gprc_mgpu* mgpu, int* n_ranks_out);
+/* GPR$initialize, one Cholesky attempt (as gprc_gpr_fit) / the ten-step jitter loop (as gprc_gpr_fit_retry) */
+GPRC_API int gprc_mgpu_gpr_fit(gprc_mgpu* mgpu, int kernel, const double* params, int n_params, const double* X, int64_t d,
+                      int64_t n, const double* y, double noise, gprc_mgpu_model** model_out);
+GPRC_API int gprc_mgpu_gpr_fit_retry(gprc_mgpu* mgpu, int kernel, const double* params, int n_params, const double* X, int64_t d,
+                            int64_t n, const double* y, double noise, gprc_mgpu_model** model_out, double* noise_used,
+                            int* attempts);
+/* GPR$predict(X_star, pointwise_var = TRUE): rank r predicts the r-th contiguous slice of the test points */
+GPRC_API int gprc_mgpu_gpr_predict(gprc_mgpu_model* model, const double* X_star, int64_t n_star, double* mean_out,
+                          double* var_out);
+GPRC_API int gprc_mgpu_gpr_get_alpha(gprc_mgpu_model* model, double* alpha_out);
+GPRC_API int gprc_mgpu_gpr_get_logp(gprc_mgpu_model* model, double* logp_out);
+GPRC_API int gprc_mgpu_gpr_get_noise(gprc_mgpu_model* model, double* noise_out);
+/* rank r's replica as an ordinary (borrowed) model handle: gprc_gpr_predict(pointwise = 0), gprc_model_get_L, ...
+ * It belongs to the gprc_mgpu_model and dies with it. */
+GPRC_API int gprc_mgpu_model_rank(gprc_mgpu_model* model, int rank, gprc_model** model_out);
+GPRC_API int gprc_mgpu_model_free(gprc_mgpu_model* model);
+
 /* ---- sampling: multivariate_normal(n, mean, covariance, tol = 1e-6)  (R/GPRclass.R:360-370) --------------------------
  * L = t(chol(covariance)); if the Cholesky fails (the usual case for a posterior covariance K(X*,X*) - t(v) %*% v,
  * which is numerically rank deficient) L = eigen$vectors %*% diag(sqrt(pmax(eigen$values, 0))) after
@@ -253,7 +291,8 @@ GPRC_API int gprc_combine_all(gprc_ctx* ctx, const double* axis_values, const in
 /* ---- measurement: per-kernel-kind HIP-event timing (bench.py's live roofline numbers) ------------ *
  * When enabled, every launch is bracketed by two hipEvents on the stream it is launched on.  Kinds:
  * 0 fill, 1 potf2_inv, 2 trsm_panel, 3 in-panel GEMM (K=128), 4 trailing update, 5 predict right
- * update (K=512), 6 trsv, 7 row reductions, 8 covariance SYRK.  flops/bytes are the ALGORITHMIC
+ * update (K=512), 6 trsv, 7 row reductions, 8 covariance SYRK, 9 derivative row sums, 10 Jacobi sweep, 11 predict
+ * left-looking update, 12 trailing left-looking update, 13 fused panel factorisation.  flops/bytes are the ALGORITHMIC
  * figures of DESIGN.md for the launches seen, not counter readings. */
 GPRC_API int gprc_prof_enable(int on);
 GPRC_API int gprc_prof_reset(void);

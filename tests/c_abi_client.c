@@ -4,6 +4,7 @@
  * Built and run by tests/test_gpu_c_abi.py (gcc, links libgprc_native.so only).  Exit code 0 = all checks passed. */
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "gprc_native.h"
@@ -104,6 +105,76 @@ int main(void) {
   CHECK(gprc_combine_all(ctx, axes, lens, 2, grid) == 0, "combine_all");
   CHECK(grid[0] == 0.0 && grid[1] == 10.0 && grid[2] == 0.0 && grid[3] == 20.0 && grid[6] == 1.0 && grid[7] == 10.0 && grid[11] == 30.0, "combine_all order");
   CHECK(gprc_ctx_trim(ctx) == 0, "ctx_trim");
+
+  /* ---- multi-GPU from ONE process (gprc_mgpu_*): G = 1, 2, 3 ranks -- VIRTUAL ranks, all on device 0, exchanging
+   * panels by device copies -- must reproduce gprc_gpr_fit / gprc_gpr_predict bit for bit.  n = 2900: 6 panels, so every
+   * rank owns several, look-ahead and the batched far updates are exercised; then no look-ahead; then the RCCL exchange
+   * with the one rank a one-GPU box allows (ncclCommInitAll + grouped ncclBroadcast). */
+  {
+    const int64_t nn = 2900, dd = 3, nst = 777;
+    double* Xm = (double*)malloc(sizeof(double) * dd * nn);
+    double* ym = (double*)malloc(sizeof(double) * nn);
+    double* Xsm = (double*)malloc(sizeof(double) * dd * nst);
+    double *a_ref = (double*)malloc(sizeof(double) * nn), *a_got = (double*)malloc(sizeof(double) * nn);
+    double *mean_ref = (double*)malloc(sizeof(double) * nst), *var_ref = (double*)malloc(sizeof(double) * nst);
+    double *mean_got = (double*)malloc(sizeof(double) * nst), *var_got = (double*)malloc(sizeof(double) * nst);
+    unsigned long long st = 88172645463325252ULL;   /* xorshift64: the client's own generator */
+    #define NEXT_U01() (st ^= st << 13, st ^= st >> 7, st ^= st << 17, (double)(st >> 11) / 9007199254740992.0)
+    for (int64_t i = 0; i < nn; ++i) {
+      double acc = 0.0;
+      for (int64_t r = 0; r < dd; ++r) { const double v = 2.0 * NEXT_U01() - 1.0; Xm[i * dd + r] = v; acc += v * v * v; }
+      ym[i] = 0.1 * acc + 0.05 * (NEXT_U01() - 0.5);
+    }
+    for (int64_t i = 0; i < dd * nst; ++i) Xsm[i] = 2.0 * NEXT_U01() - 1.0;
+    const double lm = 0.6;
+    double logp_ref = 0.0, logp_got = 0.0;
+    gprc_model* ref = NULL;
+    rc = gprc_gpr_fit(ctx, GPRC_SQREXP, &lm, 1, Xm, dd, nn, ym, 0.1, &ref);
+    CHECK(rc == 0, "reference fit rc=%d (%s)", rc, gprc_last_error());
+    CHECK(gprc_gpr_get_alpha(ref, a_ref) == 0 && gprc_gpr_get_logp(ref, &logp_ref) == 0, "reference getters");
+    CHECK(gprc_gpr_predict(ref, Xsm, nst, 1, mean_ref, var_ref) == 0, "reference predict");
+    const int devs[3] = {0, 0, 0};
+    for (int variant = 0; variant < 5; ++variant) {   /* G = 1, 2, 3 with look-ahead; G = 2 without; RCCL with one rank */
+      const int G = variant < 3 ? variant + 1 : (variant == 3 ? 2 : 1);
+      const int flags = variant == 3 ? GPRC_MGPU_NO_LOOKAHEAD : (variant == 4 ? GPRC_MGPU_RCCL : 0);
+      gprc_mgpu* mg = NULL;
+      gprc_mgpu_model* mm = NULL;
+      rc = gprc_mgpu_create(devs, G, flags, &mg);
+      CHECK(rc == 0, "mgpu_create variant %d rc=%d (%s)", variant, rc, gprc_last_error());
+      if (rc != 0) continue;
+      int gr = 0;
+      CHECK(gprc_mgpu_ranks(mg, &gr) == 0 && gr == G, "mgpu_ranks");
+      for (int rep = 0; rep < 2 && rc == 0; ++rep) {   /* twice: streams, events and flags are reused across fits */
+        rc = gprc_mgpu_gpr_fit_retry(mg, GPRC_SQREXP, &lm, 1, Xm, dd, nn, ym, 0.1, &mm, &noise_used, &attempts);
+        CHECK(rc == 0 && attempts == 1 && noise_used == 0.1, "mgpu fit variant %d rc=%d (%s)", variant, rc, gprc_last_error());
+        if (rc != 0) break;
+        CHECK(gprc_mgpu_gpr_get_alpha(mm, a_got) == 0 && gprc_mgpu_gpr_get_logp(mm, &logp_got) == 0, "mgpu getters");
+        CHECK(memcmp(a_got, a_ref, sizeof(double) * nn) == 0, "variant %d: alpha differs from gprc_gpr_fit", variant);
+        CHECK(logp_got == logp_ref, "variant %d: logp %.17g vs %.17g", variant, logp_got, logp_ref);
+        CHECK(gprc_mgpu_gpr_predict(mm, Xsm, nst, mean_got, var_got) == 0, "mgpu predict (%s)", gprc_last_error());
+        CHECK(memcmp(mean_got, mean_ref, sizeof(double) * nst) == 0 && memcmp(var_got, var_ref, sizeof(double) * nst) == 0,
+              "variant %d: sliced predict differs from gprc_gpr_predict", variant);
+        gprc_model* r_last = NULL;                     /* every rank holds the whole factor: the LAST rank's replica predicts alone */
+        CHECK(gprc_mgpu_model_rank(mm, G - 1, &r_last) == 0 && r_last != NULL, "model_rank");
+        CHECK(gprc_gpr_predict(r_last, Xsm, 64, 1, mean_got, var_got) == 0 && memcmp(mean_got, mean_ref, sizeof(double) * 64) == 0 &&
+              memcmp(var_got, var_ref, sizeof(double) * 64) == 0, "variant %d: rank %d's replica of L", variant, G - 1);
+        gprc_mgpu_model_free(mm);
+        mm = NULL;
+      }
+      /* LAPACK info and the jitter loop travel through the multi-rank sweep too */
+      rc = gprc_mgpu_gpr_fit(mg, GPRC_LINEAR, &sigma, 1, Xn, 1, 2, yn, 0.0, &mm);
+      CHECK(rc == 1 && mm == NULL, "mgpu info rc=%d", rc);
+      rc = gprc_mgpu_gpr_fit_retry(mg, GPRC_LINEAR, &sigma, 1, Xn, 1, 2, yn, 0.0, &mm, &noise_used, &attempts);
+      CHECK(rc == 0 && attempts == 4 && noise_used == 0.03, "mgpu jitter rc=%d attempts=%d", rc, attempts);
+      gprc_mgpu_model_free(mm);
+      gprc_mgpu_destroy(mg);
+    }
+    const int twice[2] = {0, 0};
+    gprc_mgpu* bad = NULL;
+    CHECK(gprc_mgpu_create(twice, 2, GPRC_MGPU_RCCL, &bad) == GPRC_ERR_ARG && bad == NULL, "RCCL refuses virtual ranks");
+    gprc_model_free(ref);
+    free(Xm); free(ym); free(Xsm); free(a_ref); free(a_got); free(mean_ref); free(var_ref); free(mean_got); free(var_got);
+  }
 
   gprc_ctx_destroy(ctx);
   printf(fails ? "c_abi_client: %d FAILED\n" : "c_abi_client: all checks passed\n", fails);
