@@ -11,6 +11,7 @@
 //                     trailing update over the packed block-column layout (lower tiles only).
 // The trailing update is the dominant kernel of the whole path: n^3/3 of the fit and n^2 n* of the
 // predict go through gemm_tile_128().
+#include <algorithm>
 #include <cstdlib>
 
 #include "gprc_internal.h"
@@ -575,8 +576,9 @@ __global__ __launch_bounds__(256, 2) void trailing_kernel(double* packed, int64_
 // Same products in the same order (k ascending from the loaded C value), so the result is bit-identical; what
 // changes is that a C tile is loaded and stored once instead of j times -- the per-tile prologue (C preload + first
 // DMA, ~7 % of a K = 512 tile during which the tile's waves issue no MFMA) is paid once per j NB of K.
+// [kp0, kp1): the source panels of this launch (kp0 = 0, kp1 = j: the whole pass; GPRC_KCHUNK splits it into K-chunks)
 __global__ __launch_bounds__(256, 2) void solve_left_kernel(double* vt, int64_t ldv, const double* packed, int64_t n_pad, int j,
-                                                            int tiles_m, int tiles_n, int group) {
+                                                            int tiles_m, int tiles_n, int group, int kp0, int kp1) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const unsigned ntiles = (unsigned)tiles_m * (unsigned)tiles_n;
   const unsigned id = xcd_remap(blockIdx.x, ntiles);
@@ -586,7 +588,8 @@ __global__ __launch_bounds__(256, 2) void solve_left_kernel(double* vt, int64_t 
   const int tr = first_m + (int)(id % width) % gsize;
   const int tc = (int)(id % width) / gsize;
   const int64_t col = (int64_t)j * NB + (int64_t)tc * 128;
-  gemm_tile_128<false, true>(vt + (int64_t)tr * 128 + col * ldv, ldv, vt + (int64_t)tr * 128, ldv, packed, n_pad, j * NB, smem, col);
+  gemm_tile_128<false, true>(vt + (int64_t)tr * 128 + col * ldv, ldv, vt + (int64_t)tr * 128 + (int64_t)kp0 * NB * ldv, ldv, packed, n_pad,
+                             (kp1 - kp0) * NB, smem, col, 0, kp0 * (NB / 16));
 }
 
 
@@ -800,11 +803,19 @@ int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, con
   if (m_pad % 128) { set_error("solve_left: m_pad must be a multiple of 128"); return GPRC_ERR_ARG; }
   if ((j + G) * NB > n_pad) { set_error("solve_left: panel group beyond the factor"); return GPRC_ERR_ARG; }
   GPRC_TRY(ensure_gemm_attrs());
-  const int64_t K = j * NB, N = G * NB, tiles = (m_pad / 128) * (N / 128);
-  ProfScope ps(s, PK_SOLVE_LEFT, 2.0 * (double)m_pad * N * (double)K, 8.0 * (2.0 * m_pad * N + (double)m_pad * K + (double)N * K));
-  hipLaunchKernelGGL(solve_left_kernel, dim3((unsigned)tiles), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, vt, ldv, packed, n_pad,
-                     (int)j, (int)(m_pad / 128), (int)(N / 128), 8);
-  GPRC_LAUNCH_CHECK();
+  const int64_t N = G * NB, tiles = (m_pad / 128) * (N / 128);
+  // GPRC_KCHUNK=<panels>: the pass is cut into launches of at most that many source panels (K = 512 x panels): the tiles an
+  // XCD runs concurrently are re-aligned at every launch boundary, so its L2 keeps serving the shared operand strips;
+  // the price is one more C tile load/store per chunk.  Same products, same order: bit-identical.  Default: one launch.
+  static const int64_t kchunk = [] { const char* e = std::getenv("GPRC_KCHUNK"); return e ? std::atoll(e) : 0; }();
+  const int64_t step = kchunk > 0 ? kchunk : j;
+  for (int64_t kp0 = 0; kp0 < j; kp0 += step) {
+    const int64_t kp1 = std::min(j, kp0 + step), K = (kp1 - kp0) * NB;
+    ProfScope ps(s, PK_SOLVE_LEFT, 2.0 * (double)m_pad * N * (double)K, 8.0 * (2.0 * m_pad * N + (double)m_pad * K + (double)N * K));
+    hipLaunchKernelGGL(solve_left_kernel, dim3((unsigned)tiles), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, vt, ldv, packed, n_pad,
+                       (int)j, (int)(m_pad / 128), (int)(N / 128), 8, (int)kp0, (int)kp1);
+    GPRC_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -894,9 +905,13 @@ int launch_trailing_range(hipStream_t s, double* packed, int64_t n_pad, int64_t 
   return 0;
 }
 
-// left-looking update of target panels [q_begin, q_end) with every panel before q_begin
+// left-looking update of target panels [q_begin, q_end) with every panel before q_begin (GPRC_KCHUNK: in K-chunks, see solve_left)
 int launch_trailing_left(hipStream_t s, double* packed, int64_t n_pad, int64_t q_begin, int64_t q_end) {
-  return launch_trailing_range(s, packed, n_pad, 0, q_begin, q_begin, q_end, 1);
+  static const int64_t kchunk = [] { const char* e = std::getenv("GPRC_KCHUNK"); return e ? std::atoll(e) : 0; }();
+  if (kchunk <= 0) return launch_trailing_range(s, packed, n_pad, 0, q_begin, q_begin, q_end, 1);
+  for (int64_t p0 = 0; p0 < q_begin; p0 += kchunk)
+    GPRC_TRY(launch_trailing_range(s, packed, n_pad, p0, std::min(q_begin, p0 + kchunk), q_begin, q_end, 1));
+  return 0;
 }
 
 }  // namespace gprc
