@@ -77,6 +77,7 @@ struct gprc_ctx {
                                // + another 64 for launches on the look-ahead stream
   // one-GPU look-ahead (factor_all_async): the panel chain runs on a high-priority side stream beside the trailing update
   hipStream_t side_stream = nullptr;
+  hipStream_t upd_stream = nullptr;   // CU-masked stream of the bulk trailing updates while a look-ahead sweep runs (see factor_all_lookahead)
   hipEvent_t ev_pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned ev_next = 0;
   double* scal_dev = nullptr;  // 8 doubles of scalar results
@@ -322,23 +323,56 @@ int stream_after(gprc_ctx* ctx, hipStream_t to, hipStream_t from) {
 int factor_all_lookahead(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev) {
   hipStream_t s = ctx->stream;
   const int64_t P = n_pad / NB;
+  // The chain's workgroups need a whole CU each (149 KB of LDS) and the trailing update keeps every CU busy with two GEMM
+  // workgroups, so on shared CUs the chain crawls (measured: 0.42 -> 0.96 ms per panel at n = 16384) and the overlap buys
+  // nothing.  With GPRC_LA_MASK = r (default 4) r CUs out of every 32 are set aside for the chain: the side stream is
+  // created with that CU mask, the bulk updates of the sweep go to a stream with the complementary mask.  0: no masks
+  // (one priority stream beside the caller's).
+  static const int reserve = [] { const char* e = std::getenv("GPRC_LA_MASK"); const int v = e ? std::atoi(e) : 4; return v < 0 || v > 16 ? 4 : v; }();
   if (!ctx->side_stream) {
-    int lo = 0, hi = 0;
-    GPRC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    GPRC_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi));
+    bool masked = false;
+    if (reserve > 0) {
+      hipDeviceProp_t prop;
+      GPRC_HIP(hipGetDeviceProperties(&prop, ctx->device));
+      const int words = (prop.multiProcessorCount + 31) / 32;
+      std::vector<uint32_t> chain(words, 0u), bulk(words, 0u);
+      for (int w = 0; w < words; ++w)
+        for (int b = 0; b < 32; ++b) {
+          if (w * 32 + b >= prop.multiProcessorCount) break;
+          // every (32 / reserve)-th CU: whatever the bit -> (XCD, shader engine) mapping is, the chain's CUs are spread evenly
+          const bool mine = (b % (32 / reserve)) == (32 / reserve) - 1 && (b / (32 / reserve)) < reserve;
+          (mine ? chain : bulk)[w] |= 1u << b;
+        }
+      hipError_t e1 = hipExtStreamCreateWithCUMask(&ctx->side_stream, (uint32_t)words, chain.data());
+      hipError_t e2 = e1 == hipSuccess ? hipExtStreamCreateWithCUMask(&ctx->upd_stream, (uint32_t)words, bulk.data()) : e1;
+      masked = e1 == hipSuccess && e2 == hipSuccess;
+      if (!masked) {
+        (void)hipGetLastError();
+        if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); ctx->side_stream = nullptr; }
+        ctx->upd_stream = nullptr;
+      }
+    }
+    if (!masked) {
+      int lo = 0, hi = 0;
+      GPRC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      GPRC_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi));
+    }
   }
   hipStream_t side = ctx->side_stream;
+  hipStream_t bulk = ctx->upd_stream ? ctx->upd_stream : s;   // where the updates run
   void* sync_side = static_cast<char*>(ctx->sync_dev) + 64;
+  if (bulk != s) GPRC_TRY(stream_after(ctx, bulk, s));
   GPRC_TRY(stream_after(ctx, side, s));                       // the fill (and the caller's memset of info) precede the chain
   GPRC_TRY(launch_panel_fused(side, packed, n_pad, 0, winv, info_dev, sync_side));
   for (int64_t p = 0; p + 1 < P; ++p) {
-    GPRC_TRY(stream_after(ctx, s, side));                     // panel p is factored
-    GPRC_TRY(launch_trailing_update(s, packed, n_pad, p, p + 1, p + 2, 1));        // panel p + 1 first ...
-    GPRC_TRY(stream_after(ctx, side, s));
+    GPRC_TRY(stream_after(ctx, bulk, side));                  // panel p is factored
+    GPRC_TRY(launch_trailing_update(bulk, packed, n_pad, p, p + 1, p + 2, 1));        // panel p + 1 first ...
+    GPRC_TRY(stream_after(ctx, side, bulk));
     GPRC_TRY(launch_panel_fused(side, packed, n_pad, p + 1, winv, info_dev, sync_side));   // ... its chain on the side stream
-    if (p + 2 < P) GPRC_TRY(launch_trailing_update(s, packed, n_pad, p, p + 2, P, 1));     // ... beside the rest of update p
+    if (p + 2 < P) GPRC_TRY(launch_trailing_update(bulk, packed, n_pad, p, p + 2, P, 1));  // ... beside the rest of update p
   }
   GPRC_TRY(stream_after(ctx, s, side));
+  if (bulk != s) GPRC_TRY(stream_after(ctx, s, bulk));
   return 0;
 }
 
@@ -676,6 +710,7 @@ int gprc_ctx_destroy(gprc_ctx* ctx) {
   if (ctx->scal_dev) (void)hipFree(ctx->scal_dev);
   if (ctx->sync_dev) (void)hipFree(ctx->sync_dev);
   if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+  if (ctx->upd_stream) { (void)hipStreamSynchronize(ctx->upd_stream); (void)hipStreamDestroy(ctx->upd_stream); }
   for (hipEvent_t ev : ctx->ev_pool)
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

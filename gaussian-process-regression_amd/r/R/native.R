@@ -40,11 +40,23 @@ covariance_matrix <- function(A, B, covariance_function) {
   outer(1:ncol(A), 1:ncol(B), function(i, j) covariance_function(A[, i, drop = F], B[, j, drop = F]))
 }
 
+# Multi-GPU: options(gprc.devices = 0:7) makes GPR$new / $predict(pointwise_var = TRUE) run the block-cyclic sweep over
+# those GPUs from this one R process (gprc_mgpu_* of include/gprc_native.h: R cannot be forked per GPU);
+# options(gprc.rccl = TRUE) selects the RCCL broadcast for the panel exchange (default: peer copies).
+.gprc_devices <- function() {
+  dv <- getOption("gprc.devices", NULL)
+  if (is.null(dv) || length(dv) < 2L) NULL else as.integer(dv)
+}
+
 # body of GPR$initialize after the input checks (R/GPRclass.R:134-153), native branch
 .gpr_initialize_native <- function(private, X, y, noise, k) {
   tag <- attr(k, "gprc_kernel")
   storage.mode(X) <- "double"
-  res <- .Call(gprc_R_gpr_fit, tag$id, tag$params, X, as.double(y), as.double(noise))
+  dv <- .gprc_devices()
+  res <- if (is.null(dv)) .Call(gprc_R_gpr_fit, tag$id, tag$params, X, as.double(y), as.double(noise))
+         else .Call(gprc_R_mgpu_gpr_fit, dv, if (isTRUE(getOption("gprc.rccl", FALSE))) 1L else 0L, tag$id, tag$params, X,
+                    as.double(y), as.double(noise))
+  private$.multi <- !is.null(dv)
   if (res[[3]] > 1L) warning(sprintf("Noise got changed to %s to avoid errors in cholesky decomposition", res[[2]]))
   private$.handle <- res[[1]]
   private$.noise <- res[[2]]
@@ -56,6 +68,10 @@ covariance_matrix <- function(A, B, covariance_function) {
 # body of GPR$predict (R/GPRclass.R:160-169), native branch
 .gpr_predict_native <- function(private, X_star, pointwise_var) {
   storage.mode(X_star) <- "double"
+  if (isTRUE(private$.multi)) {
+    if (!isTRUE(pointwise_var)) stop("gprc: the multi-GPU handle predicts pointwise variances; use one GPU for the full covariance")
+    return(.Call(gprc_R_mgpu_gpr_predict, private$.handle, X_star))
+  }
   .Call(gprc_R_gpr_predict, private$.handle, X_star, isTRUE(pointwise_var))
 }
 

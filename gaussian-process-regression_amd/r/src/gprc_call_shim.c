@@ -112,6 +112,81 @@ SEXP gprc_R_gpr_predict(SEXP handle, SEXP X_star, SEXP pointwise) {
   return res;
 }
 
+/* ---- multi-GPU from R's one process: options(gprc.devices = c(0, 1, ..., 7)) selects it (native.R) ------------------
+ * One gprc_mgpu per distinct (devices, flags) request, kept for the session: creating the streams / RCCL communicators
+ * is not free.  The model handle is a gprc_mgpu_model behind its own external-pointer class. */
+static gprc_mgpu* g_mgpu = NULL;
+static int g_mgpu_devs[64], g_mgpu_n = 0, g_mgpu_flags = -1;
+
+static gprc_mgpu* mgpu_for(SEXP devices, SEXP flags) {
+  const int n = LENGTH(devices), fl = Rf_asInteger(flags);
+  if (n < 1 || n > 64) Rf_error("gprc: 1..64 devices");
+  int same = g_mgpu != NULL && n == g_mgpu_n && fl == g_mgpu_flags;
+  for (int i = 0; same && i < n; ++i) same = INTEGER(devices)[i] == g_mgpu_devs[i];
+  if (!same) {
+    if (g_mgpu) { gprc_mgpu_destroy(g_mgpu); g_mgpu = NULL; }
+    if (gprc_mgpu_create(INTEGER(devices), n, fl, &g_mgpu) != 0) Rf_error("gprc: %s", gprc_last_error());
+    for (int i = 0; i < n; ++i) g_mgpu_devs[i] = INTEGER(devices)[i];
+    g_mgpu_n = n;
+    g_mgpu_flags = fl;
+  }
+  return g_mgpu;
+}
+
+static void mgpu_model_finalizer(SEXP ptr) {
+  gprc_mgpu_model* m = (gprc_mgpu_model*)R_ExternalPtrAddr(ptr);
+  if (m) { gprc_mgpu_model_free(m); R_ClearExternalPtr(ptr); }
+}
+
+/* GPR$initialize over several GPUs  --  R/GPRclass.R:138-153.  Returns list(handle, noise, attempts, alpha, logp). */
+SEXP gprc_R_mgpu_gpr_fit(SEXP devices, SEXP flags, SEXP kernel, SEXP params, SEXP X, SEXP y, SEXP noise) {
+  const int64_t d = Rf_nrows(X), n = Rf_ncols(X);
+  gprc_mgpu* mg = mgpu_for(devices, flags);
+  gprc_mgpu_model* m = NULL;
+  double noise_used = 0.0, logp = 0.0;
+  int attempts = 0;
+  SEXP res = PROTECT(Rf_allocVector(VECSXP, 5));   /* all R allocations before the model exists (see new_model_ptr) */
+  SEXP ptr = R_MakeExternalPtr(NULL, Rf_install("gprc_mgpu_model"), R_NilValue);
+  SET_VECTOR_ELT(res, 0, ptr);
+  R_RegisterCFinalizerEx(ptr, mgpu_model_finalizer, TRUE);
+  SEXP alpha = Rf_allocVector(REALSXP, (R_xlen_t)n);
+  SET_VECTOR_ELT(res, 3, alpha);
+  SEXP s_noise = Rf_allocVector(REALSXP, 1);
+  SET_VECTOR_ELT(res, 1, s_noise);
+  SEXP s_att = Rf_allocVector(INTSXP, 1);
+  SET_VECTOR_ELT(res, 2, s_att);
+  SEXP s_logp = Rf_allocVector(REALSXP, 1);
+  SET_VECTOR_ELT(res, 4, s_logp);
+  int rc = gprc_mgpu_gpr_fit_retry(mg, Rf_asInteger(kernel), REAL(params), LENGTH(params), REAL(X), d, n, REAL(y), Rf_asReal(noise), &m,
+                                   &noise_used, &attempts);
+  if (rc != 0) {
+    UNPROTECT(1);
+    if (rc == GPRC_ERR_NOT_PD)
+      Rf_error("Inputs lead to non positive definite covariance matrix. Try using a larger noise or a smaller lengthscale.");
+    Rf_error("gprc: %s", gprc_last_error());
+  }
+  R_SetExternalPtrAddr(ptr, m);
+  gprc_mgpu_gpr_get_alpha(m, REAL(alpha));
+  gprc_mgpu_gpr_get_logp(m, &logp);
+  REAL(s_noise)[0] = noise_used;
+  INTEGER(s_att)[0] = attempts;
+  REAL(s_logp)[0] = logp;
+  UNPROTECT(1);
+  return res;
+}
+
+/* GPR$predict(X_star, pointwise_var = TRUE) over several GPUs: the test points are sliced over the ranks */
+SEXP gprc_R_mgpu_gpr_predict(SEXP handle, SEXP X_star) {
+  gprc_mgpu_model* m = (gprc_mgpu_model*)R_ExternalPtrAddr(handle);
+  if (!m) Rf_error("gprc: model handle is NULL (object restored from a saved workspace?)");
+  const int64_t ns = Rf_ncols(X_star);
+  SEXP res = PROTECT(Rf_allocMatrix(REALSXP, (int)ns, 2));
+  int rc = gprc_mgpu_gpr_predict(m, REAL(X_star), ns, REAL(res), REAL(res) + ns);
+  UNPROTECT(1);
+  if (rc != 0) Rf_error("gprc: %s", gprc_last_error());
+  return res;
+}
+
 /* `$L` active binding: materialised lazily (n x n doubles over PCIe) */
 SEXP gprc_R_model_L(SEXP handle) {
   gprc_model* m = model_of(handle);
@@ -244,6 +319,8 @@ static const R_CallMethodDef call_methods[] = {
     {"gprc_R_mvn_sample", (DL_FUNC)&gprc_R_mvn_sample, 4},
     {"gprc_R_combine_all", (DL_FUNC)&gprc_R_combine_all, 2},
     {"gprc_R_device_count", (DL_FUNC)&gprc_R_device_count, 0},
+    {"gprc_R_mgpu_gpr_fit", (DL_FUNC)&gprc_R_mgpu_gpr_fit, 7},
+    {"gprc_R_mgpu_gpr_predict", (DL_FUNC)&gprc_R_mgpu_gpr_predict, 2},
     {NULL, NULL, 0}};
 
 void R_init_gprc(DllInfo* dll) {
@@ -253,5 +330,6 @@ void R_init_gprc(DllInfo* dll) {
 
 void R_unload_gprc(DllInfo* dll) {
   (void)dll;
+  if (g_mgpu) { gprc_mgpu_destroy(g_mgpu); g_mgpu = NULL; }
   if (g_ctx) { gprc_ctx_destroy(g_ctx); g_ctx = NULL; }
 }
