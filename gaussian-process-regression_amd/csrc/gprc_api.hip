@@ -325,10 +325,12 @@ int factor_all_lookahead(gprc_ctx* ctx, double* packed, int64_t n_pad, double* w
   const int64_t P = n_pad / NB;
   // The chain's workgroups need a whole CU each (149 KB of LDS) and the trailing update keeps every CU busy with two GEMM
   // workgroups, so on shared CUs the chain crawls (measured: 0.42 -> 0.96 ms per panel at n = 16384) and the overlap buys
-  // nothing.  With GPRC_LA_MASK = r (default 4) r CUs out of every 32 are set aside for the chain: the side stream is
-  // created with that CU mask, the bulk updates of the sweep go to a stream with the complementary mask.  0: no masks
-  // (one priority stream beside the caller's).
-  static const int reserve = [] { const char* e = std::getenv("GPRC_LA_MASK"); const int v = e ? std::atoi(e) : 4; return v < 0 || v > 16 ? 4 : v; }();
+  // little.  GPRC_LA_MASK = r sets r CUs out of every 32 aside for the chain: the side stream is created with that CU
+  // mask, the bulk updates of the sweep go to a stream with the complementary mask.  Default 0 (no masks: one priority
+  // stream beside the caller's) because the masks measured WORSE on MI355X: kernels on a CU-masked stream lose far
+  // more than the masked share (trailing update 43 -> 22 / 31 / 29 TFLOP/s with 2 / 4 / 8 of 32 CUs set aside; fit at
+  // n = 8192: 12.2 -> 14.6 / 13.5 / 13.3 ms; GPC iteration at n = 16384: 41.7 -> 54.2 / 42.0 / 42.0 ms).
+  static const int reserve = [] { const char* e = std::getenv("GPRC_LA_MASK"); const int v = e ? std::atoi(e) : 0; return v < 0 || v > 16 ? 0 : v; }();
   if (!ctx->side_stream) {
     bool masked = false;
     if (reserve > 0) {

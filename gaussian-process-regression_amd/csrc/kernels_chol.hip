@@ -397,8 +397,10 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
       for (int m = 0; m < 4; ++m) acc[m][n][r] = SET ? 0.0 : Cw[m * 16 + (int64_t)(n * 16 + 4 * r) * ldc];
 
   int64_t ldak, ldbk;
-  const double* Ag = strip_ktile<SEGA>(A, lda, arow, kt0, lane, wave, ldak);  // this lane's 16 bytes of k-slice `wave`
-  const double* Bg = strip_ktile<SEG>(B, ldb, brow, kt0, lane, wave, ldbk);
+  // kt0 (first k-tile of the pass) addresses the PACKED operands only: a plain strip is handed over already pointing at
+  // its first k-tile (the running pointer below restarts from it)
+  const double* Ag = strip_ktile<SEGA>(A, lda, arow, SEGA ? kt0 : 0, lane, wave, ldak);  // this lane's 16 bytes of k-slice `wave`
+  const double* Bg = strip_ktile<SEG>(B, ldb, brow, SEG ? kt0 : 0, lane, wave, ldbk);
   const int srow = wave * G_LDT;                          // LDS row of that slice (wave-uniform)
   const int foff = fr + fk * G_LDT;                       // this lane's MFMA operand element
 
@@ -418,8 +420,8 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   if (KT > 1) {
-    Ag = strip_ktile<SEGA>(A, lda, arow, kt0 + 1, lane, wave, ldak);
-    Bg = strip_ktile<SEG>(B, ldb, brow, kt0 + 1, lane, wave, ldbk);
+    Ag = strip_ktile<SEGA>(A, lda, arow, (SEGA ? kt0 : 0) + 1, lane, wave, ldak);
+    Bg = strip_ktile<SEG>(B, ldb, brow, (SEG ? kt0 : 0) + 1, lane, wave, ldbk);
     dma_ktile(Ag, ldak, Bg, ldbk, As + G_BUF + srow, Bs + G_BUF + srow);
   }
   if constexpr (!SEGA) Ag = A + 2 * lane + (int64_t)(2 * G_KB + wave) * lda;  // next tile to request: kt + 2

@@ -138,3 +138,32 @@ def test_flag_trsv_in_a_fresh_process():
         "print('FLAG-TRSV-OK')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GPRC_TRSV="flag"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "FLAG-TRSV-OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_k_chunked_left_looking_passes_are_bit_identical():
+    """GPRC_KCHUNK cuts the long-K left-looking passes (predict solve and Cholesky trailing update) into several launches
+    over K ranges; same products in the same order, so the factor and the prediction must not change by a bit.  The
+    switch is read once per process: the chunked run happens in a child process and the two digests are compared.
+    n = 3100 (7 panels) with GPRC_FACTOR=1 (every panel its own left-looking group) and GPRC_SOLVE=left, so passes with
+    K up to 6 panels exist and chunks of 1 and 4 panels cut them unevenly."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import hashlib, numpy as np\n"
+        "from gprc_amd import GPR, cov_func, sqrexp\n"
+        "rng = np.random.default_rng(41)\n"
+        "X = rng.uniform(-1, 1, (3, 3100)); y = rng.normal(size=3100); Xs = rng.uniform(-1, 1, (3, 900))\n"
+        "g = GPR(X, y, 0.1, cov_func(sqrexp, l=0.7))\n"
+        "h = hashlib.sha256(); [h.update(np.ascontiguousarray(a).tobytes()) for a in (g.alpha, g.L, g.predict(Xs))]\n"
+        "print('DIGEST', h.hexdigest())\n") % (os.path.dirname(here), here)
+    digests = {}
+    for kc in ("0", "1", "4"):
+        env = dict(os.environ, GPRC_KCHUNK=kc, GPRC_FACTOR="1", GPRC_SOLVE="left")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests[kc] = [ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0]
+    assert digests["1"] == digests["0"] and digests["4"] == digests["0"], digests
