@@ -450,8 +450,14 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 has landed (this wave's share)
       __syncthreads();                                   // ... everyone's share; and buffer `cur` is drained
       if (kt + 2 < KT) {
-        if constexpr (SEGA) Ag = strip_ktile<true>(A, lda, arow, kt0 + kt + 2, lane, wave, ldak);
-        if constexpr (SEG) Bg = strip_ktile<true>(B, ldb, brow, kt0 + kt + 2, lane, wave, ldbk);
+        // packed operands: inside a panel the next k-tile is 16 columns further on (same leading dimension); only at a
+        // panel boundary (every NB / 16 k-tiles) is the address rebuilt from the panel geometry -- the full index
+        // arithmetic (64-bit multiplies) on every k-tile cost ~2 % of the long-K passes
+        if constexpr (SEGA || SEG) {
+          const bool boundary = ((kt0 + kt + 2) % (NB / 16)) == 0;
+          if constexpr (SEGA) { if (boundary) Ag = strip_ktile<true>(A, lda, arow, kt0 + kt + 2, lane, wave, ldak); else Ag += (int64_t)G_KB * ldak; }
+          if constexpr (SEG) { if (boundary) Bg = strip_ktile<true>(B, ldb, brow, kt0 + kt + 2, lane, wave, ldbk); else Bg += (int64_t)G_KB * ldbk; }
+        }
         dma_ktile(Ag, ldak, Bg, ldbk, As + cur + srow, Bs + cur + srow);
         if constexpr (!SEGA) Ag += (int64_t)G_KB * lda;
         if constexpr (!SEG) Bg += (int64_t)G_KB * ldb;
