@@ -158,12 +158,19 @@ __device__ __forceinline__ void diag16(double* D, double* Wd, double* wdiag, int
     const int c = ty + 4 * k;
     reg[k] = (c <= i) ? D[i + c * BLD] : 0.0;
   }
+  // The dependent chain of one column is pivot -> rsqrt -> multiplier -> rank-1 update -> next pivot.  The pivot comes out
+  // of its lane with two v_readlane (a compile-time lane: no LDS crossbar round trip in front of the rsqrt); the other five
+  // operands travel by ds_bpermute and have landed by the time the Newton steps are through.  Nothing is stored inside
+  // the loop: a lane's four column entries of L are kept (lsave) and written after the sweep, and the column's own
+  // register is switched to the inverse entry with selects -- no exec-masked branches on the chain.
+  double lsave[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int j = kb * 4 + jj;
-      const double d = __shfl(reg[kb], jj * 16 + j, 64);    // pivot: row j, held by ty == jj
+      const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(reg[kb]), jj * 16 + j),
+                                        __builtin_amdgcn_readlane(__double2loint(reg[kb]), jj * 16 + j));  // pivot: row j, held by ty == jj
       const double wij = __shfl(reg[kb], jj * 16 + i, 64);  // column j at this lane's row
       double lv[4];
 #pragma unroll
@@ -181,12 +188,16 @@ __device__ __forceinline__ void diag16(double* D, double* Wd, double* wdiag, int
       const double mult = -lij * rinv;
 #pragma unroll
       for (int k = 0; k < 4; ++k) reg[k] = fma(mult, lv[k], reg[k]);
-      if (ty == jj) {
-        if (below) { D[i + j * BLD] = lij; reg[kb] = mult; }
-        else if (i == j) { D[j + j * BLD] = ljj; reg[kb] = 1.0; }
-      }
-      if (i == j) my_rinv = rinv;
+      const bool mine = ty == jj;                       // this lane holds column j of row i
+      lsave[kb] = mine ? (below ? lij : ljj) : lsave[kb];
+      reg[kb] = (mine && below) ? mult : ((mine && i == j) ? 1.0 : reg[kb]);
+      my_rinv = (i == j) ? rinv : my_rinv;
     }
+  }
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const int j = kb * 4 + ty;
+    if (i >= j) D[i + j * BLD] = lsave[kb];             // L: the column entries at and below the diagonal
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -645,23 +656,30 @@ __global__ __launch_bounds__(256, 2) void trailing_range_kernel(double* packed, 
 // per panel) leaves the GPU almost empty while each stage drains: ~570 us per panel, which is most of the fit at
 // n = 8192..16384 and most of one rank's share of an 8-rank sweep.  Here the stages of different 128-row strips overlap
 // and only the true dependencies remain, carried by agent-scope flags inside one grid of 512-thread workgroups:
-//   factor workgroup (ticket 0, 8 waves)   for j = 0..3: wait U_j (j > 0), factor + invert block (j, j) in LDS
-//                                           (potf2_blocked_body<8>), publish W_j
-//   diagonal strips s = 0..3 (tickets 1..4, one 4-wave team): blocks (s, 0..s-1) as below, publish R_s after the last
-//                                           one; then update block (s, s) (K = 128 s) and publish U_s
+//   factor workgroup (ticket 0, 8 waves)   the whole critical chain, with no hand-off on it:
+//                                           for j = 0..3: factor + invert block (j, j) in LDS (potf2_blocked_body<8>),
+//                                           publish W_j; then, itself, the two tiles the NEXT diagonal block waits for:
+//                                           L(j+1, j) = C'(j+1, j) Winv_j^T (publish R_{j+1}) and
+//                                           C(j+1, j+1) -= L(j+1, j) L(j+1, j)^T
+//   diagonal strips s = 1..3 (tickets 2..4, one 4-wave team): blocks (s, 0..s-2) like any strip; then everything of
+//                                           blocks (s, s-1) and (s, s) that does not need L(s-1, s-1) yet -- the updates
+//                                           with the columns left of block s-1 -- and publish E_s
 //   other strips, two per workgroup (two 4-wave teams with their own LDS halves, in lockstep: the same flags, the same
 //                                           barrier count): for j = 0..3: wait R_j (j > 0), C(s,j) -= L(s,<j) L(j,<j)^T,
 //                                           wait W_j, C(s,j) := C(s,j) Winv_j^T
-// Every tile is the same gemm_tile_128 call with the same operands and K order as in the launch-per-stage form, and the
-// diagonal block goes through the same 16x16-block arithmetic: the results are bit-identical.
-// Roles are dealt by a ticket counter in START order and every wait targets a smaller ticket, so a waiting workgroup
-// only ever waits for workgroups that are already running -- no deadlock whatever the dispatch order, the number of
-// resident workgroups (149 KB of LDS: one per CU) or what else is running on the GPU.
+// Every tile is a gemm_tile_128 call with the same operands and the same K order as in the launch-per-stage form (an update
+// split in two calls continues the same accumulator chain from the stored value), and the diagonal block goes through the
+// same 16x16-block arithmetic: the results are bit-identical.
+// No deadlock, whatever the dispatch order, the number of resident workgroups (149 KB of LDS: one per CU) or what else runs
+// on the GPU: roles are dealt by a ticket counter in START order; every flag is published by one of the first five tickets
+// (factor role and diagonal strips); those five wait only on each other, in an order without cycles (the factor role
+// publishes W_0, R_1, W_1, R_2 ... before it waits for the E_s that needs them); and a workgroup with a later ticket can
+// only be running -- and spinning -- when all five earlier ones have started.
 // Hand-off protocol: MI355X_MICROARCH.md "inter-workgroup visibility" (plain stores, every wave's vmcnt(0), workgroup
 // barrier, one lane's agent release fence + vmcnt(0), relaxed agent store of the flag; one lane polls with relaxed agent
 // loads, agent acquire fence + vmcnt(0), workgroup barrier, plain / LDS-DMA loads).
 // ------------------------------------------------------------------------------------------------
-struct PanelSync { int ticket; int failed; int W[4]; int U[4]; int R[4]; int pad[2]; };   // 16 ints, zeroed before the launch
+struct PanelSync { int ticket; int failed; int W[4]; int E[4]; int R[4]; int pad[2]; };   // 16 ints, zeroed before the launch
 
 __device__ __forceinline__ void panel_flag_wait(int* flag, PanelSync* sy) {   // the whole workgroup calls it
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own stores: its team-mates re-read them after the barrier
@@ -690,6 +708,13 @@ __device__ __forceinline__ void panel_flag_publish(int* flag) {               //
   }
 }
 
+// Workgroup barriers gemm_tile_128 executes for a K-deep tile WITHOUT the SSQ epilogue: one after the first DMA and one
+// per further k-tile.  Waves of a workgroup that sit a tile out call this so that the barrier counts match.
+__device__ __forceinline__ void gemm_tile_shadow_barriers(int K) {
+  const int KT = K / G_KB;
+  for (int b = 0; b < KT; ++b) __builtin_amdgcn_s_barrier();
+}
+
 __global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_t n_pad, int p, double* winv, int* info, PanelSync* sy) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int sh_id;
@@ -701,45 +726,59 @@ __global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_
   double* pan = packed + panel_offset(n_pad, p);
   double* wp = winv + (int64_t)p * TPP * NBI * NBI;
   const int S = (int)(ld / 128);
+  const int team = t >> 8, tid = t & 255;
 
-  if (id == 0) {                                   // ---- factor role
+  if (id == 0) {                                   // ---- factor role: the critical chain
     for (int j = 0; j < TPP; ++j) {
-      if (j > 0) panel_flag_wait(&sy->U[j], sy);
       potf2_blocked_body<8>(sm, pan + (int64_t)j * NBI + (int64_t)j * NBI * ld, ld, wp + (int64_t)j * NBI * NBI, info, p * NB + j * NBI);
-      panel_flag_publish(&sy->W[j]);
+      panel_flag_publish(&sy->W[j]);               // (its vmcnt(0) + barrier also make L(j,j) / Winv_j visible to this workgroup's own DMA)
+      if (j + 1 == TPP) break;
+      // the two tiles the next diagonal block is waiting for, by team 0 (team 1 shadows the barriers)
+      double* Cn = pan + (int64_t)(j + 1) * NBI + (int64_t)j * NBI * ld;            // block (j+1, j)
+      double* Dn = pan + (int64_t)(j + 1) * NBI + (int64_t)(j + 1) * NBI * ld;      // block (j+1, j+1)
+      if (j > 0) panel_flag_wait(&sy->E[j + 1], sy);                                // their updates with the columns left of block j
+      if (team == 0) gemm_tile_128<true>(Cn, ld, Cn, ld, wp + (int64_t)j * NBI * NBI, 128, 128, sm, 0, 0, 0, nullptr, tid);
+      else gemm_tile_shadow_barriers(128);
+      panel_flag_publish(&sy->R[j + 1]);           // rows of strip j+1 left of its diagonal block are final
+      if (team == 0) gemm_tile_128<false>(Dn, ld, Cn, ld, Cn, ld, 128, sm, 0, 0, 0, nullptr, tid);
+      else gemm_tile_shadow_barriers(128);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                             // the updated block is reloaded by all 8 waves in potf2
     }
     return;
   }
   // ---- strip roles
-  const int team = t >> 8, tid = t & 255;
   int s;
   if (id <= TPP) {                                 // a diagonal strip: one team
     if (team == 1) return;
     s = id - 1;
+    if (s == 0) return;                            // block (0, 0) needs nothing but the factor role
   } else {
     s = TPP + 2 * (id - TPP - 1) + team;
-    const bool lone = (TPP + 2 * (id - TPP - 1) + 1) >= S;   // an odd strip count: the last workgroup has one team
-    if (s >= S) return;                            // (team 1 of that workgroup; team 0 then runs alone, `lone` only documents it)
-    (void)lone;
+    if (s >= S) return;                            // odd strip count: the last workgroup runs one team
   }
   double* smem = sm + team * G_SMEM_DOUBLES;
   const double* Arow = pan + (int64_t)s * 128;     // my 128 rows of the panel
-  const int jmax = s < TPP ? s : TPP - 1;
-  for (int j = 0; j <= jmax; ++j) {
+  const int jlast = s < TPP ? s - 2 : TPP - 1;     // a diagonal strip solves blocks (s, 0..s-2) itself
+  for (int j = 0; j <= jlast; ++j) {
     const int64_t cj = (int64_t)j * NBI;
     double* C = pan + (int64_t)s * 128 + cj * ld;
     __syncthreads();                               // the previous tile's LDS reads are over before this one's first DMA lands
     if (j > 0) {
-      if (s != j) panel_flag_wait(&sy->R[j], sy);  // rows of strip j left of its diagonal block are final
+      panel_flag_wait(&sy->R[j], sy);              // rows of strip j left of its diagonal block are final
       gemm_tile_128<false>(C, ld, Arow, ld, pan + cj, ld, (int)cj, smem, 0, 0, 0, nullptr, tid);
-    }
-    if (s == j) {                                  // my diagonal block has all its in-panel updates: hand it to the factor role
-      panel_flag_publish(&sy->U[j]);
-      break;
     }
     panel_flag_wait(&sy->W[j], sy);
     gemm_tile_128<true>(C, ld, C, ld, wp + (int64_t)j * NBI * NBI, 128, 128, smem, 0, 0, 0, nullptr, tid);
-    if (s < TPP && j == s - 1) panel_flag_publish(&sy->R[s]);
+  }
+  if (s < TPP && s >= 2) {                         // diagonal strip: the early part of blocks (s, s-1) and (s, s): K = 128 (s-1)
+    const int64_t K = (int64_t)(s - 1) * NBI;
+    __syncthreads();
+    panel_flag_wait(&sy->R[s - 1], sy);
+    gemm_tile_128<false>(pan + (int64_t)s * 128 + K * ld, ld, Arow, ld, pan + K, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
+    __syncthreads();
+    gemm_tile_128<false>(pan + (int64_t)s * 128 + (int64_t)s * NBI * ld, ld, Arow, ld, Arow, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
+    panel_flag_publish(&sy->E[s]);
   }
 }
 
