@@ -362,7 +362,7 @@ int factor_all_lookahead(gprc_ctx* ctx, double* packed, int64_t n_pad, double* w
   }
   hipStream_t side = ctx->side_stream;
   hipStream_t bulk = ctx->upd_stream ? ctx->upd_stream : s;   // where the updates run
-  void* sync_side = static_cast<char*>(ctx->sync_dev) + 64;
+  void* sync_side = static_cast<char*>(ctx->sync_dev) + 256;
   if (bulk != s) GPRC_TRY(stream_after(ctx, bulk, s));
   GPRC_TRY(stream_after(ctx, side, s));                       // the fill (and the caller's memset of info) precede the chain
   GPRC_TRY(launch_panel_fused(side, packed, n_pad, 0, winv, info_dev, sync_side));
@@ -682,7 +682,8 @@ int gprc_ctx_create(int device, void* stream, gprc_ctx** ctx_out) {
   }
   hipError_t e = hipMalloc(&ctx->info_dev, 64);
   if (e == hipSuccess) e = hipMalloc(&ctx->scal_dev, 64);
-  if (e == hipSuccess) e = hipMalloc(&ctx->sync_dev, 256);
+  if (e == hipSuccess) e = hipMalloc(&ctx->sync_dev, 512);
+  if (e == hipSuccess) e = hipMemset(ctx->sync_dev, 0, 512);
   if (e != hipSuccess) { gprc_ctx_destroy(ctx); return hip_fail(e, "hipMalloc(ctx)", __FILE__, __LINE__); }
   if (const char* vp = std::getenv("GPRC_VT_PAD")) {
     const long long v = std::atoll(vp);
@@ -1308,6 +1309,14 @@ int gprc_combine_all(gprc_ctx* ctx, const double* axis_values, const int64_t* le
   GPRC_TRY(launch_combine_all(s, v.dev, lengths, d, o.dev));
   GPRC_TRY(o.finish(s));
   GPRC_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int gprc_prof_panel_trace(gprc_ctx* ctx, int side, int64_t* ticks_out, int n) {
+  GPRC_TRY(use_device(ctx));
+  if (!ticks_out || n < 1 || n > 24) { set_error("prof_panel_trace: 1..24 stamps"); return GPRC_ERR_ARG; }
+  GPRC_HIP(hipDeviceSynchronize());
+  GPRC_HIP(hipMemcpy(ticks_out, static_cast<char*>(ctx->sync_dev) + (side ? 256 : 0) + 64, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -715,7 +715,10 @@ __device__ __forceinline__ void gemm_tile_shadow_barriers(int K) {
   for (int b = 0; b < KT; ++b) __builtin_amdgcn_s_barrier();
 }
 
-__global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_t n_pad, int p, double* winv, int* info, PanelSync* sy) {
+// trace (may be null): the factor role's lane 0 leaves s_memrealtime stamps (100 MHz) of its stages there -- measurement only
+#define PANEL_STAMP(k) do { if (trace && t == 0) trace[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_t n_pad, int p, double* winv, int* info, PanelSync* sy,
+                                                          unsigned long long* trace) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int sh_id;
   const int t = threadIdx.x;
@@ -729,21 +732,28 @@ __global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_
   const int team = t >> 8, tid = t & 255;
 
   if (id == 0) {                                   // ---- factor role: the critical chain
+    PANEL_STAMP(0);
     for (int j = 0; j < TPP; ++j) {
       potf2_blocked_body<8>(sm, pan + (int64_t)j * NBI + (int64_t)j * NBI * ld, ld, wp + (int64_t)j * NBI * NBI, info, p * NB + j * NBI);
+      PANEL_STAMP(1 + 6 * j);
       panel_flag_publish(&sy->W[j]);               // (its vmcnt(0) + barrier also make L(j,j) / Winv_j visible to this workgroup's own DMA)
+      PANEL_STAMP(2 + 6 * j);
       if (j + 1 == TPP) break;
       // the two tiles the next diagonal block is waiting for, by team 0 (team 1 shadows the barriers)
       double* Cn = pan + (int64_t)(j + 1) * NBI + (int64_t)j * NBI * ld;            // block (j+1, j)
       double* Dn = pan + (int64_t)(j + 1) * NBI + (int64_t)(j + 1) * NBI * ld;      // block (j+1, j+1)
       if (j > 0) panel_flag_wait(&sy->E[j + 1], sy);                                // their updates with the columns left of block j
+      PANEL_STAMP(3 + 6 * j);
       if (team == 0) gemm_tile_128<true>(Cn, ld, Cn, ld, wp + (int64_t)j * NBI * NBI, 128, 128, sm, 0, 0, 0, nullptr, tid);
       else gemm_tile_shadow_barriers(128);
+      PANEL_STAMP(4 + 6 * j);
       panel_flag_publish(&sy->R[j + 1]);           // rows of strip j+1 left of its diagonal block are final
+      PANEL_STAMP(5 + 6 * j);
       if (team == 0) gemm_tile_128<false>(Dn, ld, Cn, ld, Cn, ld, 128, sm, 0, 0, 0, nullptr, tid);
       else gemm_tile_shadow_barriers(128);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                             // the updated block is reloaded by all 8 waves in potf2
+      PANEL_STAMP(6 + 6 * j);
     }
     return;
   }
@@ -822,7 +832,11 @@ int launch_panel_fused(hipStream_t s, double* packed, int64_t n_pad, int64_t p, 
   double fl = 0.0;
   for (int j = 0; j < TPP; ++j) fl += 2.0 * (double)(ld - j * NBI) * NBI * (j * NBI) + (double)(ld - (j + 1) * NBI) * NBI * NBI + 2.0 * NBI * NBI * NBI / 3.0;
   ProfScope ps(s, PK_PANEL_FUSED, fl, 8.0 * 2.0 * (double)ld * NB);
-  hipLaunchKernelGGL(panel_fused_kernel, dim3(grid), dim3(512), smem, s, packed, n_pad, (int)p, winv, info_dev, reinterpret_cast<PanelSync*>(sync16));
+  // GPRC_PANEL_TRACE=<p>: the factor role of panel p stamps its stages (24 x 8 bytes at sync + 64 .. sync + 256; read back with
+  // gprc_prof_panel_trace).  Measurement only.
+  static const long long trace_p = [] { const char* e = std::getenv("GPRC_PANEL_TRACE"); return e ? std::atoll(e) : -1LL; }();
+  unsigned long long* trace = (trace_p == p) ? reinterpret_cast<unsigned long long*>(static_cast<char*>(sync16) + 64) : nullptr;
+  hipLaunchKernelGGL(panel_fused_kernel, dim3(grid), dim3(512), smem, s, packed, n_pad, (int)p, winv, info_dev, reinterpret_cast<PanelSync*>(sync16), trace);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

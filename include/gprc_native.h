@@ -295,6 +295,11 @@ GPRC_API int gprc_combine_all(gprc_ctx* ctx, const double* axis_values, const in
  * left-looking update, 12 trailing left-looking update, 13 fused panel factorisation.  flops/bytes are the ALGORITHMIC
  * figures of DESIGN.md for the launches seen, not counter readings. */
 GPRC_API int gprc_prof_enable(int on);
+/* With the environment variable GPRC_PANEL_TRACE=<p> set, the factor role of the fused panel kernel of panel p leaves
+ * s_memrealtime stamps (100 MHz ticks) of its stages: [0] start, then per 128-column sub-step j: [1+6j] diagonal block
+ * factored, [2+6j] W_j published, [3+6j] E_{j+1} seen, [4+6j] L(j+1,j) solved, [5+6j] R_{j+1} published, [6+6j] block
+ * (j+1,j+1) updated.  side != 0: the context's look-ahead stream's launches.  Measurement only. */
+GPRC_API int gprc_prof_panel_trace(gprc_ctx* ctx, int side, int64_t* ticks_out, int n);
 GPRC_API int gprc_prof_reset(void);
 GPRC_API int gprc_prof_kinds(void);
 GPRC_API int gprc_prof_summary(int kind, int64_t* count_out, double* ms_out, double* flops_out, double* bytes_out);
