@@ -513,6 +513,109 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256 x 128 macro-tile on 8 waves (512 threads, one workgroup per CU): the same wave-level 64 x 64 MFMA core as
+// gemm_tile_128, but the four row-waves share ONE B strip and the A strip is twice as tall -- 384 strip rows staged per k-tile
+// for 256 x 128 outputs instead of 2 x 256 for two independent 128 x 128 workgroups: -25 % LDS-DMA traffic per flop.  Every
+// output element still accumulates k ascending in the same v_mfma_f64_16x16x4 steps from the loaded C value: bit-identical.
+// A: plain column-major strip (256 rows), B: rows [brow, brow + 128) of the PACKED factor starting at k-tile kt0 (the predict's
+// left-looking pass).  LDS: A [2][16][272] + B [2][16][144] doubles = 106,496 B.
+// ------------------------------------------------------------------------------------------------
+constexpr int T2_LDA = 272, T2_LDB = 144;
+constexpr int T2_BUFA = G_KB * T2_LDA, T2_BUFB = G_KB * T2_LDB;
+constexpr int T2_SMEM_DOUBLES = 2 * T2_BUFA + 2 * T2_BUFB;
+
+__device__ __forceinline__ void read_ops2(const double* Ac, const double* Bc, int kk, double (&a)[4], double (&b)[4]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) a[m] = Ac[kk * 4 * T2_LDA + m * 16];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) b[n] = Bc[kk * 4 * T2_LDB + n * 16];
+}
+
+__device__ __forceinline__ void gemm_tile_256x128_seg(double* C, int64_t ldc, const double* A, int64_t lda, const double* Bpk, int64_t n_pad,
+                                                      int K, double* smem, int64_t brow, int kt0) {
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // 0..7
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fk = lane >> 4, fr = lane & 15;
+  double* As = smem;
+  double* Bs = smem + 2 * T2_BUFA;
+  double* Cw = C + (wr * 64 + fr) + (int64_t)(wc * 64 + fk) * ldc;
+  double4_t acc[4][4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m][n][r] = Cw[m * 16 + (int64_t)(n * 16 + 4 * r) * ldc];
+
+  // wave w stages k-slices w and w + 8 of a k-tile: A rows 0..127, A rows 128..255, B rows 0..127 -- three 1-KiB wave-instructions each
+  int64_t ldbk;
+  const double* Ag = A + 2 * lane + (int64_t)wave * lda;                                   // k-slice `wave` of k-tile 0
+  const double* Bg = strip_ktile<true>(Bpk, n_pad, brow, kt0, lane, wave, ldbk);
+  auto dma2 = [&](const double* ag, const double* bg, int64_t ldb_, double* Asb, double* Bsb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(ag + (int64_t)(8 * i) * lda), (lptr_t)(Asb + (wave + 8 * i) * T2_LDA), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ag + 128 + (int64_t)(8 * i) * lda), (lptr_t)(Asb + (wave + 8 * i) * T2_LDA + 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(bg + (int64_t)(8 * i) * ldb_), (lptr_t)(Bsb + (wave + 8 * i) * T2_LDB), 16, 0, 0);
+    }
+  };
+  constexpr int LGKM0 = 0xC07F;
+  const int KT = K / G_KB;
+  dma2(Ag, Bg, ldbk, As, Bs);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  if (KT > 1) {
+    Ag += (int64_t)G_KB * lda;
+    Bg = strip_ktile<true>(Bpk, n_pad, brow, kt0 + 1, lane, wave, ldbk);
+    dma2(Ag, Bg, ldbk, As + T2_BUFA, Bs + T2_BUFB);
+  }
+  const int foffA = fr + fk * T2_LDA, foffB = fr + fk * T2_LDB;
+  double a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
+  read_ops2(As + wr * 64 + foffA, Bs + wc * 64 + foffB, 0, a0, b0);
+  read_ops2(As + wr * 64 + foffA, Bs + wc * 64 + foffB, 1, a1, b1);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    const double* Ac = As + cur * T2_BUFA + wr * 64 + foffA;
+    const double* Bc = Bs + cur * T2_BUFB + wc * 64 + foffB;
+    const double* An = As + (1 - cur) * T2_BUFA + wr * 64 + foffA;
+    const double* Bn = Bs + (1 - cur) * T2_BUFB + wc * 64 + foffB;
+    __builtin_amdgcn_s_waitcnt(LGKM0);
+    read_ops2(Ac, Bc, 2, a2, b2);
+    mma_step<1>(a0, b0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(LGKM0);
+    read_ops2(Ac, Bc, 3, a3, b3);
+    mma_step<1>(a1, b1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(LGKM0);
+    if (kt + 1 < KT) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 2 < KT) {
+        Ag += (int64_t)G_KB * lda;
+        if (((kt0 + kt + 2) % (NB / 16)) == 0) Bg = strip_ktile<true>(Bpk, n_pad, brow, kt0 + kt + 2, lane, wave, ldbk);
+        else Bg += (int64_t)G_KB * ldbk;
+        dma2(Ag, Bg, ldbk, As + cur * T2_BUFA, Bs + cur * T2_BUFB);
+      }
+      read_ops2(An, Bn, 0, a0, b0);
+    }
+    mma_step<1>(a2, b2, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(LGKM0);
+    if (kt + 1 < KT) read_ops2(An, Bn, 1, a1, b1);
+    mma_step<1>(a3, b3, acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) Cw[m * 16 + (int64_t)(n * 16 + 4 * r) * ldc] = acc[m][n][r];
+}
+
 // blockIdx -> logical id so that each XCD (blocks b, b+8, ... share one) owns a contiguous id range
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   const unsigned q = nwg >> 3, r = nwg & 7, x = bid & 7;
@@ -611,6 +714,22 @@ __global__ __launch_bounds__(256, 2) void solve_left_kernel(double* vt, int64_t 
                              (kp1 - kp0) * NB, smem, col, 0, kp0 * (NB / 16));
 }
 
+
+// the same pass on 256 x 128 macro-tiles (GPRC_TILE256=1; m_pad a multiple of 256)
+__global__ __launch_bounds__(512) void solve_left_kernel256(double* vt, int64_t ldv, const double* packed, int64_t n_pad, int j,
+                                                            int tiles_m, int tiles_n, int group, int kp0, int kp1) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const unsigned ntiles = (unsigned)tiles_m * (unsigned)tiles_n;
+  const unsigned id = xcd_remap(blockIdx.x, ntiles);
+  const int width = group * tiles_n;
+  const int g = id / width, first_m = g * group;
+  const int gsize = (tiles_m - first_m < group) ? (tiles_m - first_m) : group;
+  const int tr = first_m + (int)(id % width) % gsize;
+  const int tc = (int)(id % width) / gsize;
+  const int64_t col = (int64_t)j * NB + (int64_t)tc * 128;
+  gemm_tile_256x128_seg(vt + (int64_t)tr * 256 + col * ldv, ldv, vt + (int64_t)tr * 256 + (int64_t)kp0 * NB * ldv, ldv, packed, n_pad,
+                        (kp1 - kp0) * NB, smem, col, kp0 * (NB / 16));
+}
 
 // Trailing update by a RANGE of source panels [p_begin, p_end) in one pass: every lower tile of the target panels
 // q_begin, q_begin + q_stride, ... (n_targets of them) receives
@@ -873,11 +992,27 @@ int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, con
   // the price is one more C tile load/store per chunk.  Same products, same order: bit-identical.  Default: one launch.
   static const int64_t kchunk = [] { const char* e = std::getenv("GPRC_KCHUNK"); return e ? std::atoll(e) : 0; }();
   const int64_t step = kchunk > 0 ? kchunk : j;
+  // GPRC_TILE256=1: 256 x 128 macro-tiles on 8 waves (experiment: -25 % operand staging per flop); needs m_pad % 256 == 0
+  static const bool tile256 = [] { const char* e = std::getenv("GPRC_TILE256"); return e && std::atoi(e) == 1; }();
+  const bool use256 = tile256 && m_pad % 256 == 0;
+  if (use256) {
+    static bool attr_set[MAX_DEVICES] = {};
+    int dev = 0;
+    GPRC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES || !attr_set[dev]) {
+      GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_left_kernel256), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T2_SMEM_DOUBLES * sizeof(double))));
+      if (dev >= 0 && dev < MAX_DEVICES) attr_set[dev] = true;
+    }
+  }
   for (int64_t kp0 = 0; kp0 < j; kp0 += step) {
     const int64_t kp1 = std::min(j, kp0 + step), K = (kp1 - kp0) * NB;
     ProfScope ps(s, PK_SOLVE_LEFT, 2.0 * (double)m_pad * N * (double)K, 8.0 * (2.0 * m_pad * N + (double)m_pad * K + (double)N * K));
-    hipLaunchKernelGGL(solve_left_kernel, dim3((unsigned)tiles), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, vt, ldv, packed, n_pad,
-                       (int)j, (int)(m_pad / 128), (int)(N / 128), 8, (int)kp0, (int)kp1);
+    if (use256)
+      hipLaunchKernelGGL(solve_left_kernel256, dim3((unsigned)(tiles / 2)), dim3(512), T2_SMEM_DOUBLES * sizeof(double), s, vt, ldv, packed, n_pad,
+                         (int)j, (int)(m_pad / 256), (int)(N / 128), 8, (int)kp0, (int)kp1);
+    else
+      hipLaunchKernelGGL(solve_left_kernel, dim3((unsigned)tiles), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, vt, ldv, packed, n_pad,
+                         (int)j, (int)(m_pad / 128), (int)(N / 128), 8, (int)kp0, (int)kp1);
     GPRC_LAUNCH_CHECK();
   }
   return 0;

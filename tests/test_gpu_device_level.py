@@ -167,3 +167,29 @@ def test_k_chunked_left_looking_passes_are_bit_identical():
         assert r.returncode == 0, r.stderr[-2000:]
         digests[kc] = [ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0]
     assert digests["1"] == digests["0"] and digests["4"] == digests["0"], digests
+
+
+def test_256x128_macro_tile_is_bit_identical():
+    """GPRC_TILE256=1 runs the predict's left-looking passes on 256 x 128 macro-tiles (8 waves sharing one B strip) instead of
+    128 x 128 tiles: same k order per output element, so not a bit may change.  Child processes (the switch is read once);
+    ns = 1024 rows (m_pad a multiple of 256), GPRC_SOLVE=left / 2 so that left-looking passes with K up to 5 panels run."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import hashlib, numpy as np\n"
+        "from gprc_amd import GPR, cov_func, sqrexp\n"
+        "rng = np.random.default_rng(43)\n"
+        "X = rng.uniform(-1, 1, (3, 2900)); y = rng.normal(size=2900); Xs = rng.uniform(-1, 1, (3, 1024))\n"
+        "g = GPR(X, y, 0.1, cov_func(sqrexp, l=0.7))\n"
+        "h = hashlib.sha256(); [h.update(np.ascontiguousarray(a).tobytes()) for a in (g.alpha, g.predict(Xs), g.predict(Xs[:, :512]))]\n"
+        "print('DIGEST', h.hexdigest())\n") % (os.path.dirname(here), here)
+    digests = {}
+    for t256, solve in (("0", "left"), ("1", "left"), ("1", "2")):
+        env = dict(os.environ, GPRC_TILE256=t256, GPRC_SOLVE=solve)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests[(t256, solve)] = [ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0]
+    assert len(set(digests.values())) == 1, digests
