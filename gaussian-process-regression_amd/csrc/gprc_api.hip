@@ -366,12 +366,25 @@ int factor_all_lookahead(gprc_ctx* ctx, double* packed, int64_t n_pad, double* w
   if (bulk != s) GPRC_TRY(stream_after(ctx, bulk, s));
   GPRC_TRY(stream_after(ctx, side, s));                       // the fill (and the caller's memset of info) precede the chain
   GPRC_TRY(launch_panel_fused(side, packed, n_pad, 0, winv, info_dev, sync_side));
+  // Batched far updates (as the multi-rank sweep does): only the panel factored next is brought up to date at every step;
+  // the panels behind it receive the factored panels every `batch` steps, all of them in ONE pass with the C tiles held in
+  // the accumulators (K = 512 x batch: one tile prologue and one C load/store per batch instead of per panel).  Same
+  // products in the same order per element: bit-identical.  GPRC_UPDATE_BATCH=1: per panel.
+  static const int64_t batch = [] { const char* e = std::getenv("GPRC_UPDATE_BATCH"); const long long v = e ? std::atoll(e) : 4; return v < 1 ? 1LL : v; }();
+  auto update = [&](int64_t p0, int64_t p1, int64_t q0, int64_t q1) -> int {   // panels [p0, p1) -> targets [q0, q1)
+    if (q0 >= q1 || p0 >= p1) return 0;
+    return p1 - p0 == 1 ? launch_trailing_update(bulk, packed, n_pad, p0, q0, q1, 1) : launch_trailing_range(bulk, packed, n_pad, p0, p1, q0, q1, 1);
+  };
+  int64_t far_from = 0;                                       // panels [0, far_from) have been applied to everything behind them
   for (int64_t p = 0; p + 1 < P; ++p) {
     GPRC_TRY(stream_after(ctx, bulk, side));                  // panel p is factored
-    GPRC_TRY(launch_trailing_update(bulk, packed, n_pad, p, p + 1, p + 2, 1));        // panel p + 1 first ...
+    GPRC_TRY(update(far_from, p + 1, p + 1, p + 2));          // panel p + 1 first ...
     GPRC_TRY(stream_after(ctx, side, bulk));
     GPRC_TRY(launch_panel_fused(side, packed, n_pad, p + 1, winv, info_dev, sync_side));   // ... its chain on the side stream
-    if (p + 2 < P) GPRC_TRY(launch_trailing_update(bulk, packed, n_pad, p, p + 2, P, 1));  // ... beside the rest of update p
+    if (p + 1 - far_from >= batch || p + 2 >= P) {            // ... beside the far update
+      GPRC_TRY(update(far_from, p + 1, p + 2, P));
+      far_from = p + 1;
+    }
   }
   GPRC_TRY(stream_after(ctx, s, side));
   if (bulk != s) GPRC_TRY(stream_after(ctx, s, bulk));
