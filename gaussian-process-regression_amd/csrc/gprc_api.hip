@@ -366,11 +366,12 @@ int factor_all_lookahead(gprc_ctx* ctx, double* packed, int64_t n_pad, double* w
   if (bulk != s) GPRC_TRY(stream_after(ctx, bulk, s));
   GPRC_TRY(stream_after(ctx, side, s));                       // the fill (and the caller's memset of info) precede the chain
   GPRC_TRY(launch_panel_fused(side, packed, n_pad, 0, winv, info_dev, sync_side));
-  // Batched far updates (as the multi-rank sweep does): only the panel factored next is brought up to date at every step;
-  // the panels behind it receive the factored panels every `batch` steps, all of them in ONE pass with the C tiles held in
-  // the accumulators (K = 512 x batch: one tile prologue and one C load/store per batch instead of per panel).  Same
-  // products in the same order per element: bit-identical.  GPRC_UPDATE_BATCH=1: per panel.
-  static const int64_t batch = [] { const char* e = std::getenv("GPRC_UPDATE_BATCH"); const long long v = e ? std::atoll(e) : 4; return v < 1 ? 1LL : v; }();
+  // Optional batched far updates (GPRC_LA_BATCH = b > 1, as the multi-rank sweep does): only the panel factored next is
+  // brought up to date at every step; the panels behind it receive the factored panels every b steps in ONE pass with the C
+  // tiles held in the accumulators.  Bit-identical, but measured SLOWER on one GPU -- the catch-up of the next panel
+  // (K up to 512 b on a single panel) sits on the critical path: fit at n = 8192 12.1 -> 12.9 ms, GPC iteration at
+  // n = 16384 41.9 -> 42.9 (b = 4) / 45.5 ms (b = 8).  Default 1: per panel.
+  static const int64_t batch = [] { const char* e = std::getenv("GPRC_LA_BATCH"); const long long v = e ? std::atoll(e) : 1; return v < 1 ? 1LL : v; }();
   auto update = [&](int64_t p0, int64_t p1, int64_t q0, int64_t q1) -> int {   // panels [p0, p1) -> targets [q0, q1)
     if (q0 >= q1 || p0 >= p1) return 0;
     return p1 - p0 == 1 ? launch_trailing_update(bulk, packed, n_pad, p0, q0, q1, 1) : launch_trailing_range(bulk, packed, n_pad, p0, p1, q0, q1, 1);
