@@ -110,8 +110,6 @@ int launch_row_reduce(hipStream_t s, const double* vt, int64_t ld, int64_t rows,
 int launch_logp(hipStream_t s, const double* packed, int64_t n_pad, int64_t n, const double* y, const double* alpha, double* out);
 // unpack the factor into a dense n x n lower matrix (upper = 0)
 int launch_unpack_L(hipStream_t s, const double* packed, int64_t n_pad, int64_t n, double* out, int64_t ld_out);
-// out[i] = kss[i] - ss[i]
-int launch_sub(hipStream_t s, const double* a, const double* b, double* out, int64_t n);
 // out[i] = (minuend ? minuend[i] : 0) -/+ sum_{t < nparts} part[t * stride + i], summed in t order: the tail of the fused
 // predict epilogues (mean = sum of the fill's partials; var = k(x*,x*) - sum of the solve's per-block sums of squares)
 int launch_sum_partials(hipStream_t s, const double* part, int64_t nparts, int64_t stride, int64_t rows, const double* minuend, double* out);
@@ -122,7 +120,6 @@ int launch_gpc_a(hipStream_t s, const double* b, const double* sw, const double*
 int launch_gpc_objective(hipStream_t s, const double* a, const double* f, const double* y, int64_t n, double* out);
 int launch_gpc_build_B(hipStream_t s, const double* Kfull, int64_t n_pad, const double* sw, double* packed);
 int launch_gpc_grad(hipStream_t s, const double* f, const double* y, int64_t n, double* g, double* sw);           // g=(y+1)/2-P
-int launch_scale_cols(hipStream_t s, double* vt, int64_t ld, int64_t rows, int64_t cols, const double* colscale); // vt[i,j]*=colscale[j]
 int launch_gpc_class_prob(hipStream_t s, const double* fs, const double* vf, double* out, int64_t n);              // R/GPCclass.R:116-117
 // sampling support (kernels_eig.hip)
 int launch_pack_dense(hipStream_t s, const double* A, int64_t lda, int64_t m, int64_t n_pad, double* packed);

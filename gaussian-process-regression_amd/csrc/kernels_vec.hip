@@ -479,11 +479,6 @@ __global__ __launch_bounds__(256) void unpack_kernel(const double* packed, int64
   for (int64_t j = blockIdx.y; j < n; j += gridDim.y) out[i + j * ld_out] = (i >= j) ? *packed_at(packed, n_pad, i, j) : 0.0;
 }
 
-__global__ __launch_bounds__(256) void sub_kernel(const double* a, const double* b, double* out, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = a[i] - b[i];
-}
-
 // ---- GPC (Laplace / IRLS) stages ----------------------------------------------------------------
 __device__ __forceinline__ double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }  // R/GPCclass.R:63
 
@@ -535,11 +530,6 @@ __global__ __launch_bounds__(256) void gpc_build_B_kernel(const double* K, int64
     const double v = (i == j ? 1.0 : 0.0) + (sw[i] * sw[j]) * K[i + j * n_pad];
     packed[panel_offset(n_pad, p) + (i - p * NB) + (j - p * NB) * panel_ld(n_pad, p)] = v;
   }
-}
-__global__ __launch_bounds__(256) void scale_cols_kernel(double* vt, int64_t ld, int64_t rows, int64_t cols, const double* cs) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= rows) return;
-  for (int64_t j = blockIdx.y; j < cols; j += gridDim.y) vt[i + j * ld] *= cs[j];
 }
 
 // ---- GPC class probability: P(y* = +1) = integral of sigmoid(z) * N(z; mean = fs_bar, sd = Vfs) dz ------------
@@ -682,12 +672,6 @@ int launch_unpack_L(hipStream_t s, const double* packed, int64_t n_pad, int64_t 
   GPRC_LAUNCH_CHECK();
   return 0;
 }
-int launch_sub(hipStream_t s, const double* a, const double* b, double* out, int64_t n) {
-  if (n <= 0) return 0;
-  hipLaunchKernelGGL(sub_kernel, dim3(blocks(n, 256)), dim3(256), 0, s, a, b, out, n);
-  GPRC_LAUNCH_CHECK();
-  return 0;
-}
 int launch_gpc_pre(hipStream_t s, const double* f, const double* y, int64_t n, double* sw, double* b) {
   const int64_t n_pad = pad_up(n, NB);
   hipLaunchKernelGGL(gpc_pre_kernel, dim3(blocks(n_pad, 256)), dim3(256), 0, s, f, y, n, n_pad, sw, b);
@@ -724,13 +708,6 @@ int launch_gpc_build_B(hipStream_t s, const double* Kfull, int64_t n_pad, const 
 int launch_gpc_class_prob(hipStream_t s, const double* fs, const double* vf, double* out, int64_t n) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(gpc_class_prob_kernel, dim3(blocks(n, 64)), dim3(64), 0, s, fs, vf, out, n);
-  GPRC_LAUNCH_CHECK();
-  return 0;
-}
-int launch_scale_cols(hipStream_t s, double* vt, int64_t ld, int64_t rows, int64_t cols, const double* colscale) {
-  if (rows <= 0 || cols <= 0) return 0;
-  const unsigned gy = (unsigned)(cols < 16384 ? cols : 16384);
-  hipLaunchKernelGGL(scale_cols_kernel, dim3(blocks(rows, 256), gy), dim3(256), 0, s, vt, ld, rows, cols, colscale);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

@@ -169,6 +169,38 @@ int main(void) {
       gprc_mgpu_model_free(mm);
       gprc_mgpu_destroy(mg);
     }
+    /* the same at 18 panels with three ranks on the one GPU: nine look-ahead chains (one fused, flag-synchronised launch
+     * each) run beside three ranks' trailing updates -- the hand-offs under uneven load; every word of alpha compared */
+    {
+      const int64_t n2 = 9100;
+      double* X2 = (double*)malloc(sizeof(double) * dd * n2);
+      double* y2 = (double*)malloc(sizeof(double) * n2);
+      double *a2r = (double*)malloc(sizeof(double) * n2), *a2g = (double*)malloc(sizeof(double) * n2);
+      for (int64_t i = 0; i < n2; ++i) {
+        double acc = 0.0;
+        for (int64_t r = 0; r < dd; ++r) { const double v = 2.0 * NEXT_U01() - 1.0; X2[i * dd + r] = v; acc += v * v * v; }
+        y2[i] = 0.1 * acc + 0.05 * (NEXT_U01() - 0.5);
+      }
+      gprc_model* r2 = NULL;
+      gprc_mgpu* mg3 = NULL;
+      gprc_mgpu_model* m3 = NULL;
+      double lp_r = 0.0, lp_g = 0.0;
+      CHECK(gprc_gpr_fit(ctx, GPRC_SQREXP, &lm, 1, X2, dd, n2, y2, 0.1, &r2) == 0, "reference fit n=9100 (%s)", gprc_last_error());
+      CHECK(gprc_gpr_get_alpha(r2, a2r) == 0 && gprc_gpr_get_logp(r2, &lp_r) == 0, "reference getters n=9100");
+      CHECK(gprc_mgpu_create(devs, 3, 0, &mg3) == 0, "mgpu_create G=3 (%s)", gprc_last_error());
+      for (int rep = 0; rep < 3 && mg3; ++rep) {
+        rc = gprc_mgpu_gpr_fit(mg3, GPRC_SQREXP, &lm, 1, X2, dd, n2, y2, 0.1, &m3);
+        CHECK(rc == 0, "mgpu fit n=9100 rc=%d (%s)", rc, gprc_last_error());
+        if (rc != 0) break;
+        CHECK(gprc_mgpu_gpr_get_alpha(m3, a2g) == 0 && gprc_mgpu_gpr_get_logp(m3, &lp_g) == 0, "mgpu getters n=9100");
+        CHECK(memcmp(a2g, a2r, sizeof(double) * n2) == 0 && lp_g == lp_r, "n=9100, G=3, rep %d: differs from gprc_gpr_fit", rep);
+        gprc_mgpu_model_free(m3);
+        m3 = NULL;
+      }
+      gprc_mgpu_destroy(mg3);
+      gprc_model_free(r2);
+      free(X2); free(y2); free(a2r); free(a2g);
+    }
     const int twice[2] = {0, 0};
     gprc_mgpu* bad = NULL;
     CHECK(gprc_mgpu_create(twice, 2, GPRC_MGPU_RCCL, &bad) == GPRC_ERR_ARG && bad == NULL, "RCCL refuses virtual ranks");
