@@ -422,6 +422,7 @@ int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* 
   GPRC_TRY(factor_all_async(ctx, packed, n_pad, winv, ctx->info_dev));
   GPRC_HIP(hipMemcpyAsync(info_host, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
   GPRC_HIP(hipStreamSynchronize(s));
+  if (*info_host < 0) { set_error("fused panel kernel: a device-side dependency wait timed out (info = " + std::to_string(*info_host) + "); the factor is not valid"); return GPRC_ERR_HIP; }
   return 0;
 }
 

@@ -258,6 +258,7 @@ int mgpu_attempt(gprc_mgpu* mg, gprc_mgpu_model* m, double noise, int* info_out)
     int ir = 0;
     MG_HIP(hipMemcpyAsync(&ir, m->pr[r].info, sizeof(int), hipMemcpyDeviceToHost, k.main));
     MG_HIP(hipStreamSynchronize(k.main));
+    if (ir < 0) { set_error("mgpu: a device-side dependency wait timed out on rank " + std::to_string(r) + " (info = " + std::to_string(ir) + ")"); return GPRC_ERR_HIP; }
     if (ir > 0 && (info == 0 || ir < info)) info = ir;
   }
   *info_out = info;

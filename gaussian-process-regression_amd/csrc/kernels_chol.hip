@@ -800,14 +800,18 @@ __global__ __launch_bounds__(256, 2) void trailing_range_kernel(double* packed, 
 // ------------------------------------------------------------------------------------------------
 struct PanelSync { int ticket; int failed; int W[4]; int E[4]; int R[4]; int pad[2]; };   // 16 ints, zeroed before the launch
 
-__device__ __forceinline__ void panel_flag_wait(int* flag, PanelSync* sy) {   // the whole workgroup calls it
+__device__ __forceinline__ void panel_flag_wait(int* flag, PanelSync* sy, int* info) {   // the whole workgroup calls it
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own stores: its team-mates re-read them after the barrier
   if (threadIdx.x == 0) {
     int spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1 << 25)) {   // exit condition every wave reaches (see trsv strip_wait): flag the failure, let the grid drain
+      // exit condition every wave reaches (a producer that never publishes must not leave this workgroup spinning on the GPU
+      // for ever; ~2^25 polls is tens of seconds): give up, let the grid drain, and tell the host through the ONE word it always
+      // reads after a factorisation -- info = GPRC_INFO_WAIT_TIMEOUT (< 0; LAPACK infos are > 0)
+      if (++spins > (1 << 25)) {
         __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
         break;
       }
     }
@@ -861,7 +865,7 @@ __global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_
       // the two tiles the next diagonal block is waiting for, by team 0 (team 1 shadows the barriers)
       double* Cn = pan + (int64_t)(j + 1) * NBI + (int64_t)j * NBI * ld;            // block (j+1, j)
       double* Dn = pan + (int64_t)(j + 1) * NBI + (int64_t)(j + 1) * NBI * ld;      // block (j+1, j+1)
-      if (j > 0) panel_flag_wait(&sy->E[j + 1], sy);                                // their updates with the columns left of block j
+      if (j > 0) panel_flag_wait(&sy->E[j + 1], sy, info);                                // their updates with the columns left of block j
       PANEL_STAMP(3 + 6 * j);
       if (team == 0) gemm_tile_128<true>(Cn, ld, Cn, ld, wp + (int64_t)j * NBI * NBI, 128, 128, sm, 0, 0, 0, nullptr, tid);
       else gemm_tile_shadow_barriers(128);
@@ -894,10 +898,10 @@ __global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_
     double* C = pan + (int64_t)s * 128 + cj * ld;
     __syncthreads();                               // the previous tile's LDS reads are over before this one's first DMA lands
     if (j > 0) {
-      panel_flag_wait(&sy->R[j], sy);              // rows of strip j left of its diagonal block are final
+      panel_flag_wait(&sy->R[j], sy, info);              // rows of strip j left of its diagonal block are final
       gemm_tile_128<false>(C, ld, Arow, ld, pan + cj, ld, (int)cj, smem, 0, 0, 0, nullptr, tid);
     }
-    panel_flag_wait(&sy->W[j], sy);
+    panel_flag_wait(&sy->W[j], sy, info);
     gemm_tile_128<true>(C, ld, C, ld, wp + (int64_t)j * NBI * NBI, 128, 128, smem, 0, 0, 0, nullptr, tid);
   }
   if (s < TPP && s >= 2) {                         // diagonal strip: the early part of blocks (s, s-1) and (s, s): K = 128 (s-1)
@@ -908,7 +912,7 @@ __global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_
     // (measured: with the other order the factor role waited 10-12 us for E_3)
     gemm_tile_128<false>(pan + (int64_t)s * 128 + (int64_t)s * NBI * ld, ld, Arow, ld, Arow, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
     __syncthreads();
-    panel_flag_wait(&sy->R[s - 1], sy);
+    panel_flag_wait(&sy->R[s - 1], sy, info);
     gemm_tile_128<false>(pan + (int64_t)s * 128 + K * ld, ld, Arow, ld, pan + K, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
     panel_flag_publish(&sy->E[s]);
   }

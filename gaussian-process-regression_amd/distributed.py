@@ -444,7 +444,10 @@ class DistributedGPR:
 
     def _finish_fit(self, y_pad, forward_done=False):
         ops, comm = self.ops, self.comm
-        self.info_value = comm.min_positive(ops.read_info(self.info))
+        local_info = ops.read_info(self.info)
+        if local_info < 0:   # a fused kernel's device-side dependency wait ran out (never seen; see gprc_internal.h): not a factor
+            raise nat.GprcError(nat.ERR_HIP, f"device-side dependency wait timed out on rank {comm.rank} (info = {local_info})")
+        self.info_value = comm.min_positive(local_info)
         if self.info_value != 0:
             return self.info_value
         with ops.on(False):                                   # F3: replicated, L is complete everywhere
