@@ -69,7 +69,20 @@ __device__ __forceinline__ double finish(double s, const KernelSpec& ks) {
     return exp(-q);
   }
   else if constexpr (KID == GPRC_GAMMAEXP) return exp(-r_pow(sqrt(s) / ks.p[0], ks.p[1]));
-  else { double l = ks.p[0], al = ks.p[1]; return r_pow(1.0 + s / (2.0 * al * (l * l)), -al); }
+  else {
+    // (1 + s / (2 alpha l^2))^(-alpha).  The quotient by the launch constant 2 alpha l^2 is formed exactly as a division would
+    // (reciprocal + one fma correction, as for sqexp); q >= 1, so q^(-alpha) = exp(-alpha log q) -- two transcendental
+    // evaluations of ~25 instructions each instead of the generic pow (special-case ladder + extended-precision log/exp,
+    // ~3x the work: the rational-quadratic fill ran at 1.06 TB/s against 3.5 for sqexp).  The relative difference from a
+    // correctly rounded pow is <= (alpha log q + 1) ulp -- 3e-16 for the C3 inputs, far inside the 1e-13 gate of the fills.
+    // alpha == 2 keeps R's x^2 = x * x special case (R_pow).
+    const double al = ks.p[1], c = ks.p[2], rc = ks.p[3];   // c = 2 alpha l^2, rc = 1 / c (make_fill_spec)
+    double x = s * rc;
+    x = fma(fma(-x, c, s), rc, x);
+    const double q = 1.0 + x;
+    if (al == 2.0) return 1.0 / (q * q);
+    return exp(-al * log(q));
+  }
 }
 
 // FUSE (cross-covariance chunks of the predict only): besides storing the tile, every workgroup leaves the partial
@@ -192,6 +205,10 @@ KernelSpec make_fill_spec(const KernelSpec& ks) {
   if (ks.id == GPRC_SQREXP) {
     d.p[1] = 2.0 * (ks.p[0] * ks.p[0]);
     d.p[2] = 1.0 / d.p[1];
+  }
+  if (ks.id == GPRC_RATQUAD) {
+    d.p[2] = 2.0 * ks.p[1] * (ks.p[0] * ks.p[0]);   // 2 * alpha * l^2, in R's evaluation order
+    d.p[3] = 1.0 / d.p[2];
   }
   return d;
 }
