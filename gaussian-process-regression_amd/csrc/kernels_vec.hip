@@ -230,6 +230,99 @@ __global__ __launch_bounds__(256) void trsv_gemvt_above(const double* packed, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// Whole solves, ONE launch per panel (the default of launch_trsv): the kernel that subtracts panel p's contribution from the
+// rest of the right-hand side ALSO solves the diagonal block of the next panel -- in the workgroup that owns that panel's 512
+// rows / columns, right after it has updated them.  The per-panel form above needs two dependent launches per panel (diagonal
+// block, then the wide product: 70 us, of which the one-workgroup diagonal kernel is half); here the diagonal solve of panel
+// p +- 1 rides on the product of panel p while the other workgroups are still streaming their rows.  Every row / column goes
+// through gemv_group_partial / gemvt_column_dot and the trsv_*_phase code in the same order as in the per-panel kernels:
+// identical bits (tests/test_gpu_device_level.py).  (gprc_dev_trsv_step keeps the per-panel kernels: in the multi-rank sweep the
+// next panel does not exist yet when a step runs.)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void trsv_fwd_chain_kernel(const double* packed, const double* winv, int64_t n_pad, int p, double* b) {
+  __shared__ double xs[NB];
+  __shared__ double z[NB];
+  __shared__ double red[4][NB];      // workgroup 0: [group][row of the next panel]; others: [sub * 4 + g][i] in the first 8 x 128
+  static_assert(TPP == 4, "written for four 128-blocks per panel");
+  const int t = threadIdx.x;
+  if (t < NB) xs[t] = b[(int64_t)p * NB + t];
+  __syncthreads();
+  const int64_t ld = panel_ld(n_pad, p);
+  const double* pan = packed + panel_offset(n_pad, p);
+  if (blockIdx.x == 0) {             // the 512 rows of panel p + 1, then that panel's diagonal block
+    const int r = t & (NB - 1), h = t >> 9;
+    const int64_t row = (int64_t)(p + 1) * NB + r;
+    const double* Lr = pan + (row - (int64_t)p * NB);
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+      const int g = 2 * h + gg;
+      red[g][r] = gemv_group_partial(Lr + (int64_t)(g * (NB / 4)) * ld, ld, xs + g * (NB / 4));
+    }
+    __syncthreads();
+    if (t < NB) z[t] = b[row] - ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t]));   // (row == (p+1) NB + t for t < NB)
+    __syncthreads();
+    const int64_t ld1 = panel_ld(n_pad, p + 1);
+    const double* pan1 = packed + panel_offset(n_pad, p + 1);
+    const double* W = winv + (int64_t)(p + 1) * TPP * 128 * 128;
+    double (*red8)[128] = reinterpret_cast<double (*)[128]>(&red[0][0]);
+    const int i = t & 127, ty = t >> 7;
+    trsv_fwd_phase<0>(pan1, ld1, W, z, red8, i, ty);
+    trsv_fwd_phase<1>(pan1, ld1, W + 128 * 128, z, red8, i, ty);
+    trsv_fwd_phase<2>(pan1, ld1, W + 2 * 128 * 128, z, red8, i, ty);
+    trsv_fwd_phase<3>(pan1, ld1, W + 3 * 128 * 128, z, red8, i, ty);
+    if (t < NB) b[(int64_t)(p + 1) * NB + t] = z[t];
+    return;
+  }
+  // rows behind panel p + 1: 256 per workgroup, the thread layout of trsv_gemv_below twice
+  const int sub = t >> 9, i = t & 127, g = (t >> 7) & 3;
+  const int64_t row = (int64_t)(p + 2) * NB + (int64_t)(blockIdx.x - 1) * 256 + sub * 128 + i;
+  const double* Lr = pan + (row - (int64_t)p * NB) + (int64_t)(g * (NB / 4)) * ld;
+  double (*red8)[128] = reinterpret_cast<double (*)[128]>(&red[0][0]);
+  red8[sub * 4 + g][i] = gemv_group_partial(Lr, ld, xs + g * (NB / 4));
+  __syncthreads();
+  if (g == 0) b[row] -= (red8[sub * 4][i] + red8[sub * 4 + 1][i]) + (red8[sub * 4 + 2][i] + red8[sub * 4 + 3][i]);
+}
+
+__global__ __launch_bounds__(1024) void trsv_bwd_chain_kernel(const double* packed, const double* winv, int64_t n_pad, int p, double* x) {
+  __shared__ double xs[NB];
+  __shared__ double z[NB];
+  __shared__ double v[128];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t < NB) xs[t] = x[(int64_t)p * NB + t];
+  __syncthreads();
+  if (blockIdx.x == 0) {             // the 512 columns of panel p - 1, then that panel's diagonal block
+    const int q = p - 1;
+    const int64_t ldq = panel_ld(n_pad, q);
+    const double* panq = packed + panel_offset(n_pad, q);
+    const double* blk = panq + NB;   // rows of panel p inside panel q = p - 1
+    if (t < NB) z[t] = x[(int64_t)q * NB + t];
+    __syncthreads();
+    for (int k = 0; k < NB / 16; ++k) {          // wave w: columns w * 32 .. w * 32 + 31
+      const int c = w * (NB / 16) + k;
+      const double s = gemvt_column_dot(blk + (int64_t)c * ldq, xs, lane);
+      if (lane == 0) z[c] -= s;
+    }
+    __syncthreads();
+    const double* W = winv + (int64_t)q * TPP * 128 * 128;
+    trsv_bwd_phase<3>(panq, ldq, W + 3 * 128 * 128, z, v, lane, w);
+    trsv_bwd_phase<2>(panq, ldq, W + 2 * 128 * 128, z, v, lane, w);
+    trsv_bwd_phase<1>(panq, ldq, W + 128 * 128, z, v, lane, w);
+    trsv_bwd_phase<0>(panq, ldq, W, z, v, lane, w);
+    if (t < NB) x[(int64_t)q * NB + t] = z[t];
+    return;
+  }
+  // panels q < p - 1: 128 columns per workgroup, 8 per wave
+  const int cb = blockIdx.x - 1, q = cb / TPP, c0 = (cb % TPP) * 128;
+  const int64_t ldq = panel_ld(n_pad, q);
+  const double* blk = packed + panel_offset(n_pad, q) + (int64_t)(p - q) * NB;
+  for (int k = 0; k < 8; ++k) {
+    const int c = c0 + w * 8 + k;
+    const double s = gemvt_column_dot(blk + (int64_t)c * ldq, xs, lane);
+    if (lane == 0) x[(int64_t)q * NB + c] -= s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The whole solve in ONE launch (forward and backward): "sync-free" triangular solve over 256-row strips.
 //
 // The per-panel form above costs two launches per 512 columns, 2 x 128 dependent launches at n = 65536: 9 ms per solve,
@@ -611,7 +704,8 @@ int launch_trsv_step(hipStream_t s, const double* packed, const double* winv, in
 }
 
 // work: gprc_trsv_work_size(n_pad) doubles; its first bytes hold the ticket / progress counters of the flag kernels.
-// Default: the per-panel launches.  GPRC_TRSV=flag selects the single-launch strip kernels (same bits): measured SLOWER on
+// Default: one launch per panel (trsv_*_chain_kernel).  GPRC_TRSV=steps: the two-launch per-panel form.
+// GPRC_TRSV=flag selects the single-launch strip kernels (same bits): measured SLOWER on
 // MI355X -- 12.7 ms against 9.1 ms per solve at n = 65536, 1.33 against 0.80 ms at n = 8192 -- because a strip's critical
 // path (the 256 x 512 block next to the diagonal + two diagonal phases, ~1.4 MB) is read by ONE compute unit at its
 // ~100 GB/s, where the per-panel form spreads the same bytes over four.
@@ -627,10 +721,27 @@ int launch_trsv(hipStream_t s, const double* packed, const double* winv, int64_t
     GPRC_LAUNCH_CHECK();
     return 0;
   }
-  if (!transpose)
-    for (int p = 0; p < P; ++p) GPRC_TRY(launch_trsv_step(s, packed, winv, n_pad, b, 0, p));
-  else
-    for (int p = P - 1; p >= 0; --p) GPRC_TRY(launch_trsv_step(s, packed, winv, n_pad, b, 1, p));
+  static const bool steps = [] { const char* e = std::getenv("GPRC_TRSV"); return e && std::strcmp(e, "steps") == 0; }();
+  if (steps) {   // two launches per panel (the form gprc_dev_trsv_step exposes)
+    if (!transpose)
+      for (int p = 0; p < P; ++p) GPRC_TRY(launch_trsv_step(s, packed, winv, n_pad, b, 0, p));
+    else
+      for (int p = P - 1; p >= 0; --p) GPRC_TRY(launch_trsv_step(s, packed, winv, n_pad, b, 1, p));
+    return 0;
+  }
+  // default: one launch per panel -- the product of panel p carries the diagonal solve of the next panel
+  if (!transpose) {
+    hipLaunchKernelGGL(trsv_diag_fwd, dim3(1), dim3(1024), 0, s, packed, winv, n_pad, 0, b);
+    for (int p = 0; p + 1 < P; ++p) {
+      const int64_t behind = n_pad - (int64_t)(p + 2) * NB;   // rows behind panel p + 1
+      hipLaunchKernelGGL(trsv_fwd_chain_kernel, dim3((unsigned)(1 + behind / 256)), dim3(1024), 0, s, packed, winv, n_pad, p, b);
+    }
+  } else {
+    hipLaunchKernelGGL(trsv_diag_bwd, dim3(1), dim3(1024), 0, s, packed, winv, n_pad, P - 1, b);
+    for (int p = P - 1; p >= 1; --p)
+      hipLaunchKernelGGL(trsv_bwd_chain_kernel, dim3((unsigned)(1 + (p - 1) * TPP)), dim3(1024), 0, s, packed, winv, n_pad, p, b);
+  }
+  GPRC_LAUNCH_CHECK();
   return 0;
 }
 

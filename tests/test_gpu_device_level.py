@@ -76,10 +76,11 @@ def test_sweep_variants_are_bit_identical():
     ctx.close()
 
 
-@pytest.mark.parametrize("n,reps", [(2100, 1)])
+@pytest.mark.parametrize("n,reps", [(2100, 1), (600, 1), (9100, 2)])
 def test_solve_in_panel_steps_is_bit_identical(n, reps):
-    """gprc_dev_trsv (the whole solve) against gprc_dev_trsv_step, the per-panel form the multi-rank sweep runs beside
-    the factorisation: every word equal."""
+    """gprc_dev_trsv (the whole solve: one launch per panel, the product of panel p carrying the diagonal solve of the next
+    panel) against gprc_dev_trsv_step, the two-launch per-panel form the multi-rank sweep runs beside the factorisation:
+    every word equal.  n = 600: two panels (one chain launch); n = 9100: 18 panels."""
     L, ctx, g, a = _filled(n, seed=32)
     w, info = _new(g)
     nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr()))
