@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void trsv_gemvt_above(const double* packed, in
 }
 
 // ------------------------------------------------------------------------------------------------
-// Whole solves, ONE launch per panel (the default of launch_trsv): the kernel that subtracts panel p's contribution from the
+// Whole solves, ONE launch per panel (GPRC_TRSV=chain; NOT the default -- measured slower, see launch_trsv): the kernel that subtracts panel p's contribution from the
 // rest of the right-hand side ALSO solves the diagonal block of the next panel -- in the workgroup that owns that panel's 512
 // rows / columns, right after it has updated them.  The per-panel form above needs two dependent launches per panel (diagonal
 // block, then the wide product: 70 us, of which the one-workgroup diagonal kernel is half); here the diagonal solve of panel
@@ -704,7 +704,7 @@ int launch_trsv_step(hipStream_t s, const double* packed, const double* winv, in
 }
 
 // work: gprc_trsv_work_size(n_pad) doubles; its first bytes hold the ticket / progress counters of the flag kernels.
-// Default: one launch per panel (trsv_*_chain_kernel).  GPRC_TRSV=steps: the two-launch per-panel form.
+// Default: the two-launch per-panel form.  GPRC_TRSV=chain: one launch per panel (trsv_*_chain_kernel; slower, see below).
 // GPRC_TRSV=flag selects the single-launch strip kernels (same bits): measured SLOWER on
 // MI355X -- 12.7 ms against 9.1 ms per solve at n = 65536, 1.33 against 0.80 ms at n = 8192 -- because a strip's critical
 // path (the 256 x 512 block next to the diagonal + two diagonal phases, ~1.4 MB) is read by ONE compute unit at its
@@ -721,15 +721,17 @@ int launch_trsv(hipStream_t s, const double* packed, const double* winv, int64_t
     GPRC_LAUNCH_CHECK();
     return 0;
   }
-  static const bool steps = [] { const char* e = std::getenv("GPRC_TRSV"); return e && std::strcmp(e, "steps") == 0; }();
-  if (steps) {   // two launches per panel (the form gprc_dev_trsv_step exposes)
+  static const bool chain = [] { const char* e = std::getenv("GPRC_TRSV"); return e && std::strcmp(e, "chain") == 0; }();
+  if (!chain) {  // default: two launches per panel (the form gprc_dev_trsv_step exposes)
     if (!transpose)
       for (int p = 0; p < P; ++p) GPRC_TRY(launch_trsv_step(s, packed, winv, n_pad, b, 0, p));
     else
       for (int p = P - 1; p >= 0; --p) GPRC_TRY(launch_trsv_step(s, packed, winv, n_pad, b, 1, p));
     return 0;
   }
-  // default: one launch per panel -- the product of panel p carries the diagonal solve of the next panel
+  // GPRC_TRSV=chain: one launch per panel -- the product of panel p carries the diagonal solve of the next panel.  Same bits,
+  // measured SLOWER (0.80 -> 1.09 ms per solve at n = 8192, 9.1 -> 11.6 ms at n = 65536): the next panel's 512 x 512 product
+  // (2 MB) then goes through ONE compute unit in front of the diagonal solve, where the two-launch form spreads it over four.
   if (!transpose) {
     hipLaunchKernelGGL(trsv_diag_fwd, dim3(1), dim3(1024), 0, s, packed, winv, n_pad, 0, b);
     for (int p = 0; p + 1 < P; ++p) {

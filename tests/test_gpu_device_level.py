@@ -78,9 +78,10 @@ def test_sweep_variants_are_bit_identical():
 
 @pytest.mark.parametrize("n,reps", [(2100, 1), (600, 1), (9100, 2)])
 def test_solve_in_panel_steps_is_bit_identical(n, reps):
-    """gprc_dev_trsv (the whole solve: one launch per panel, the product of panel p carrying the diagonal solve of the next
-    panel) against gprc_dev_trsv_step, the two-launch per-panel form the multi-rank sweep runs beside the factorisation:
-    every word equal.  n = 600: two panels (one chain launch); n = 9100: 18 panels."""
+    """gprc_dev_trsv (the whole solve) against gprc_dev_trsv_step, the per-panel form the multi-rank sweep runs beside the
+    factorisation: every word equal.  n = 600: two panels; n = 9100: 18 panels.  (The alternative whole-solve kernels --
+    GPRC_TRSV=chain, one launch per panel, and GPRC_TRSV=flag, one launch per solve -- are checked the same way in
+    test_flag_trsv_in_a_fresh_process.)"""
     L, ctx, g, a = _filled(n, seed=32)
     w, info = _new(g)
     nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr()))
@@ -137,8 +138,9 @@ def test_flag_trsv_in_a_fresh_process():
         "            assert torch.equal(whole, steps), (n, tr)\n"
         "    ctx.close()\n"
         "print('FLAG-TRSV-OK')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GPRC_TRSV="flag"), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "FLAG-TRSV-OK" in r.stdout, r.stderr[-2000:]
+    for mode in ("flag", "chain"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GPRC_TRSV=mode), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "FLAG-TRSV-OK" in r.stdout, (mode, r.stderr[-2000:])
 
 
 def test_k_chunked_left_looking_passes_are_bit_identical():
