@@ -44,7 +44,7 @@ class _ReadOnly:
 class GPR:
     """GPR$new(X, y, noise = 0, k, cov_names)  --  R/GPRclass.R:127-128."""
 
-    def __init__(self, X, y, noise=0, k=None, cov_names=None, *, ctx=None):
+    def __init__(self, X, y, noise=0, k=None, cov_names=None, *, ctx=None, devices=None, rccl=False):
         if k is None:
             # the reference default: k = fit(X, y, noise, cov_names)$func (R/GPRclass.R:127); all six kernels of the
             # default list are covered (Brent for the one-parameter kernels and the polynomial degree loop, vmmin/BFGS
@@ -66,10 +66,19 @@ class GPR:
         self._X, self._y, self._k = Xm, y, k
         self._L = None
         self._model = C.c_void_p()
+        self._mgpu = self._mmodel = None
         _, pp, npar = nat.params_array(k.native_params(d))
         noise_used, attempts = C.c_double(), C.c_int()
-        rc = nat.lib().gprc_gpr_fit_retry(self._ctx.handle, k.gprc_kernel[0], pp, npar, Xm.ctypes.data, d, n, y.ctypes.data,
-                                          float(noise), C.byref(self._model), C.byref(noise_used), C.byref(attempts))
+        if devices is not None and (len(devices) > 1 or rccl):
+            # the reference's GPR$new over several GPUs from this ONE process (gprc_mgpu_*; the R side: options(gprc.devices = ...)).
+            # `devices` may list a device several times: virtual ranks sharing a GPU (peer copies only).
+            self._mgpu = _mgpu_for(tuple(int(v) for v in devices), bool(rccl))
+            self._mmodel = C.c_void_p()
+            rc = nat.lib().gprc_mgpu_gpr_fit_retry(self._mgpu, k.gprc_kernel[0], pp, npar, Xm.ctypes.data, d, n, y.ctypes.data, float(noise),
+                                                   C.byref(self._mmodel), C.byref(noise_used), C.byref(attempts))
+        else:
+            rc = nat.lib().gprc_gpr_fit_retry(self._ctx.handle, k.gprc_kernel[0], pp, npar, Xm.ctypes.data, d, n, y.ctypes.data,
+                                              float(noise), C.byref(self._model), C.byref(noise_used), C.byref(attempts))
         if rc == nat.ERR_NOT_PD:
             raise ArithmeticError("Inputs lead to non positive definite covariance matrix. "
                                   "Try using a larger noise or a smaller lengthscale.")      # :149
@@ -78,9 +87,14 @@ class GPR:
             warnings.warn(f"Noise got changed to {_r_num(noise_used.value)} to avoid errors in cholesky decomposition")
         self._noise = noise_used.value
         alpha = np.empty(n)
-        nat.check(nat.lib().gprc_gpr_get_alpha(self._model, alpha.ctypes.data))
         lp = C.c_double()
-        nat.check(nat.lib().gprc_gpr_get_logp(self._model, C.byref(lp)))
+        if self._mmodel is not None:
+            nat.check(nat.lib().gprc_mgpu_gpr_get_alpha(self._mmodel, alpha.ctypes.data))
+            nat.check(nat.lib().gprc_mgpu_gpr_get_logp(self._mmodel, C.byref(lp)))
+            nat.check(nat.lib().gprc_mgpu_model_rank(self._mmodel, 0, C.byref(self._model)))   # rank 0's replica: $L, full covariance
+        else:
+            nat.check(nat.lib().gprc_gpr_get_alpha(self._model, alpha.ctypes.data))
+            nat.check(nat.lib().gprc_gpr_get_logp(self._model, C.byref(lp)))
         self._alpha, self._logp = alpha, lp.value
 
     @classmethod
@@ -102,7 +116,10 @@ class GPR:
         mean = np.empty(ns)
         if pointwise_var:
             var = np.empty(ns)
-            nat.check(nat.lib().gprc_gpr_predict(self._model, Xs.ctypes.data, ns, 1, mean.ctypes.data, var.ctypes.data))
+            if self._mmodel is not None:   # the test points are sliced over the ranks
+                nat.check(nat.lib().gprc_mgpu_gpr_predict(self._mmodel, Xs.ctypes.data, ns, mean.ctypes.data, var.ctypes.data))
+            else:
+                nat.check(nat.lib().gprc_gpr_predict(self._model, Xs.ctypes.data, ns, 1, mean.ctypes.data, var.ctypes.data))
             return np.column_stack([mean, var])                                              # :165
         cov = np.empty((ns, ns), order="F")
         nat.check(nat.lib().gprc_gpr_predict(self._model, Xs.ctypes.data, ns, 0, mean.ctypes.data, cov.ctypes.data))
@@ -152,6 +169,10 @@ class GPR:
     logp = _ReadOnly("logp", lambda s: s._logp)
 
     def close(self):
+        if getattr(self, "_mmodel", None):
+            nat.lib().gprc_mgpu_model_free(self._mmodel)     # owns the per-rank replicas, including the borrowed self._model
+            self._mmodel = None
+            self._model = C.c_void_p()
         if getattr(self, "_model", None):
             nat.lib().gprc_model_free(self._model)
             self._model = C.c_void_p()
@@ -161,6 +182,21 @@ class GPR:
             self.close()
         except Exception:
             pass
+
+
+_mgpu_cache = {}
+
+
+def _mgpu_for(devices, rccl):
+    """One gprc_mgpu per (devices, rccl) for the life of the process: creating streams / RCCL communicators is not free."""
+    key = (devices, rccl)
+    h = _mgpu_cache.get(key)
+    if h is None:
+        h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        nat.check(nat.lib().gprc_mgpu_create(arr, len(devices), 1 if rccl else 0, C.byref(h)))
+        _mgpu_cache[key] = h
+    return h
 
 
 def _fitted(X, y, noise, kernel, ctx=None):

@@ -108,3 +108,24 @@ def test_bench_gpus2_spawns_its_own_ranks():
     assert [p["rank"] for p in out["phases_ms"]["per_rank"]] == [0, 1]
     assert out["parity_timed_config"]["ok"] and out["parity_timed_config_normwise_err"] <= 1e-9
     assert out["parity_gate_normwise_err"] <= TOL and out["value"] > 0
+
+
+@pytest.mark.parametrize("devices,rccl", [([0, 0], False), ([0, 0, 0], False), ([0], True)])
+def test_gpr_over_virtual_ranks_from_one_process(devices, rccl):
+    """GPR(..., devices=[...]): the reference's GPR$new / $predict over several ranks driven by THIS process through
+    gprc_mgpu_* (what the R binding's options(gprc.devices=) selects).  Virtual ranks share cuda:0; the RCCL exchange is
+    exercised with the one rank a one-GPU box allows.  Bitwise equal to the single-GPU object, including the full
+    posterior covariance and $L served by rank 0's replica."""
+    from gprc_amd import GPR, cov_func, rationalquadratic
+    X, y, Xs = _problem(2300, 4, 301)
+    k = cov_func(rationalquadratic, l=0.9, alpha=1.5)
+    ref = GPR(X.T, y, 0.1, k)
+    g = GPR(X.T, y, 0.1, k, devices=devices, rccl=rccl)
+    assert np.array_equal(g.alpha, ref.alpha) and g.logp == ref.logp and g.noise == ref.noise
+    assert np.array_equal(g.predict(Xs.T), ref.predict(Xs.T))
+    m1, c1 = g.predict(Xs.T[:, :40], pointwise_var=False)
+    m0, c0 = ref.predict(Xs.T[:, :40], pointwise_var=False)
+    assert np.array_equal(m1, m0) and np.array_equal(c1, c0)
+    assert np.array_equal(g.L, ref.L)
+    g.close()
+    ref.close()
