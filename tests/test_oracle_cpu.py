@@ -235,3 +235,18 @@ def test_fit_record_is_what_the_host_driver_yields_on_the_oracle():
             assert np.allclose(r["par"], case["par"], rtol=1e-9, atol=1e-12)
             assert np.allclose(r["score"], [case["score"][nm] for nm in rec["cov_names"]], rtol=1e-10, atol=1e-10)
     assert [c["holds"] for c in rec["cases"]] == [True, True, True, False, False, False]
+
+
+def test_oracle_is_clean_under_address_and_ub_sanitizers(tmp_path):
+    """tests/oracle_sanitize_driver.c: the oracle's translation unit compiled with -fsanitize=address,undefined
+    (-fno-sanitize-recover) and driven through the closed-form case, a ragged blocked fit + predict, the jitter loop, a GPC fit
+    and the eigen helpers.  GPU sanitizers are not available on this pool, so the checker itself is what gets sanitised
+    (SURVEY section 5)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "oracle_sanitize")
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fopenmp",
+                           "-ffp-contract=off", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "oracle_sanitize_driver.c"), "-lm"])
+    r = subprocess.run([exe], env=dict(os.environ, OMP_NUM_THREADS="2", ASAN_OPTIONS="detect_leaks=1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "oracle_sanitize_driver: ok" in r.stdout, r.stdout + r.stderr[-3000:]
