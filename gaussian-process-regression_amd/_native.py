@@ -188,7 +188,7 @@ def device_count() -> int:
 
 
 PROF_KINDS = ["fill", "potf2_inv", "trsm_panel", "gemm_inner_k128", "trailing_update", "solve_update_k512", "trsv",
-              "row_reduce", "cov_syrk", "deriv_rowsum", "jacobi_sweep", "solve_left", "trailing_left", "panel_fused"]
+              "row_reduce", "cov_syrk", "deriv_rowsum", "jacobi_sweep", "solve_left", "trailing_left", "panel_fused", "solve_panel"]
 
 
 def prof_summary():

@@ -447,9 +447,13 @@ int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t 
   for (int64_t g0 = 0; g0 < P; g0 += G) {
     const int64_t g1 = std::min(P, g0 + G);  // panels [g0, g1)
     GPRC_TRY(launch_solve_left(s, vt, ldv, m_pad, packed, n_pad, g0, g1 - g0));
+    static const bool panel_steps = [] { const char* e = std::getenv("GPRC_SOLVE_PANEL"); return e && std::strcmp(e, "steps") == 0; }();
     for (int64_t p = g0; p < g1; ++p) {
       const int64_t ld = panel_ld(n_pad, p);
       const double* pan = packed + panel_offset(n_pad, p);
+      if (!panel_steps) {                   // the four sub-steps of the panel in one launch (GPRC_SOLVE_PANEL=steps: seven launches, same bits)
+        GPRC_TRY(launch_solve_panel_fused(s, vt, ldv, m_pad, packed, n_pad, p, winv, sspart));
+      } else
       for (int j = 0; j < NB / NBI; ++j) {  // inside the panel, left-looking by 128-column blocks (K = 128 j, as factor_subpanel)
         const int64_t cj = p * NB + (int64_t)j * NBI;  // global column
         const double* wblk = winv + (p * (NB / NBI) + j) * NBI * NBI;

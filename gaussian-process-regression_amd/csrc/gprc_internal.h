@@ -45,7 +45,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 // ---- in-library event profiler (bench.py's live roofline numbers) ---------------------------------
 enum ProfKind { PK_FILL = 0, PK_POTF2 = 1, PK_TRSM_PANEL = 2, PK_GEMM_INNER = 3, PK_TRAILING = 4, PK_SOLVE_UPDATE = 5,
-                PK_TRSV = 6, PK_ROWREDUCE = 7, PK_COV_SYRK = 8, PK_DERIV = 9, PK_JACOBI = 10, PK_SOLVE_LEFT = 11, PK_TRAILING_LEFT = 12, PK_PANEL_FUSED = 13, PK_COUNT = 14 };
+                PK_TRSV = 6, PK_ROWREDUCE = 7, PK_COV_SYRK = 8, PK_DERIV = 9, PK_JACOBI = 10, PK_SOLVE_LEFT = 11, PK_TRAILING_LEFT = 12, PK_PANEL_FUSED = 13, PK_SOLVE_PANEL = 14, PK_COUNT = 15 };
 bool prof_enabled();
 void prof_begin(hipStream_t s, int kind);
 void prof_end(hipStream_t s, int kind, double flops, double bytes);
@@ -89,6 +89,9 @@ int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* i
 // the whole of panel p (four diagonal blocks, panel solves, in-panel updates) in ONE launch; sync16: 64 bytes of device
 // memory the launch may use for its flags (zeroed by the launcher, stream-ordered: one buffer serves a whole stream)
 int launch_panel_fused(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync16);
+// the predict's in-panel solve of panel p in one launch (see solve_panel_fused_kernel)
+int launch_solve_panel_fused(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t p,
+                             const double* winv, double* sspart);
 // X[M x 128] := X * W^T for lower-triangular 128x128 W (= inverse of a diagonal block of L)
 int launch_trsm_panel(hipStream_t s, double* X, int64_t ldx, int64_t M, const double* winv, double* ssq = nullptr);
 // C[M x N] -= A[M x K] * B[N x K]^T; lower_diag >= 0: row tile r / col tile c with r + lower_diag < c is skipped

@@ -715,6 +715,34 @@ __global__ __launch_bounds__(256, 2) void solve_left_kernel(double* vt, int64_t 
 }
 
 
+// The predict's in-panel solve in ONE launch: panel p of vt := vt L^-T once everything left of the panel has been applied.
+// Per 128-row strip of vt the four 128-column sub-steps are C(.,j) -= vt(., panel columns < j) L(j, < j)^T  (K = 128 j), then
+// C(.,j) := C(.,j) Winv_j^T [+ the per-row sums of squares of the finished block].  L and Winv are final, so strips are
+// independent: what used to be seven dependent launches per panel (each draining the GPU, each latency-bound for the 64-tile
+// slices of an 8-rank run) is one workgroup per strip running its seven tiles back to back.  The same gemm_tile_128 calls in the
+// same order per strip: bit-identical.
+template <bool SSQ>
+__global__ __launch_bounds__(256, 2) void solve_panel_fused_kernel(double* vt, int64_t ldv, const double* packed, int64_t n_pad, int p,
+                                                                   const double* winv, double* sspart, int64_t m_pad) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int64_t ld = panel_ld(n_pad, p);
+  const double* pan = packed + panel_offset(n_pad, p);
+  double* strip = vt + (int64_t)blockIdx.x * 128 + (int64_t)p * NB * ldv;   // my 128 rows, first column of the panel
+  for (int j = 0; j < TPP; ++j) {
+    double* C = strip + (int64_t)j * NBI * ldv;
+    if (j > 0) {
+      gemm_tile_128<false>(C, ldv, strip, ldv, pan + (int64_t)j * NBI, ld, j * NBI, smem);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the updated block is re-read (LDS-DMA) by all four waves
+      __syncthreads();
+    }
+    const double* wblk = winv + ((int64_t)p * TPP + j) * NBI * NBI;
+    double* ssq = SSQ ? sspart + ((int64_t)p * TPP + j) * m_pad + (int64_t)blockIdx.x * 128 : nullptr;
+    gemm_tile_128<true, false, false, SSQ>(C, ldv, C, ldv, wblk, 128, 128, smem, 0, 0, 0, ssq);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // block j is an operand of the next sub-step's update
+    __syncthreads();
+  }
+}
+
 // the same pass on 256 x 128 macro-tiles (GPRC_TILE256=1; m_pad a multiple of 256)
 __global__ __launch_bounds__(512) void solve_left_kernel256(double* vt, int64_t ldv, const double* packed, int64_t n_pad, int j,
                                                             int tiles_m, int tiles_n, int group, int kp0, int kp1) {
@@ -978,6 +1006,8 @@ static int ensure_gemm_attrs() {
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<PK_COV_SYRK>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_panel_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_panel_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_panel_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_panel_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_left_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_range_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1023,6 +1053,22 @@ int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, con
 }
 
 // ssq != nullptr: also ssq[i] = sum_j X_new[i][j]^2 for the M rows (the predict's fused colSums(v * v) partial of this block column)
+// vt[:, panel p] := vt[:, panel p] L_pp^-T (in place; everything left of panel p already applied); sspart (may be null):
+// per-row sums of squares of the four finished 128-column blocks at sspart[(4 p + j) * m_pad + row]
+int launch_solve_panel_fused(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t p,
+                             const double* winv, double* sspart) {
+  if (m_pad <= 0) return 0;
+  if (m_pad % 128) { set_error("solve_panel_fused: m_pad must be a multiple of 128"); return GPRC_ERR_ARG; }
+  GPRC_TRY(ensure_gemm_attrs());
+  const double M = (double)m_pad;
+  ProfScope ps(s, PK_SOLVE_PANEL, M * 128.0 * 128.0 * TPP + 2.0 * M * 128.0 * 128.0 * (TPP * (TPP - 1) / 2), 8.0 * 2.0 * M * NB);
+  const size_t smem = G_SMEM_DOUBLES * sizeof(double);
+  if (sspart) hipLaunchKernelGGL(solve_panel_fused_kernel<true>, dim3((unsigned)(m_pad / 128)), dim3(256), smem, s, vt, ldv, packed, n_pad, (int)p, winv, sspart, m_pad);
+  else hipLaunchKernelGGL(solve_panel_fused_kernel<false>, dim3((unsigned)(m_pad / 128)), dim3(256), smem, s, vt, ldv, packed, n_pad, (int)p, winv, sspart, m_pad);
+  GPRC_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_trsm_panel(hipStream_t s, double* X, int64_t ldx, int64_t M, const double* winv, double* ssq) {
   if (M <= 0) return 0;
   if (M % 128) { set_error("trsm_panel: M must be a multiple of 128"); return GPRC_ERR_ARG; }

@@ -292,7 +292,7 @@ GPRC_API int gprc_combine_all(gprc_ctx* ctx, const double* axis_values, const in
  * When enabled, every launch is bracketed by two hipEvents on the stream it is launched on.  Kinds:
  * 0 fill, 1 potf2_inv, 2 trsm_panel, 3 in-panel GEMM (K=128), 4 trailing update, 5 predict right
  * update (K=512), 6 trsv, 7 row reductions, 8 covariance SYRK, 9 derivative row sums, 10 Jacobi sweep, 11 predict
- * left-looking update, 12 trailing left-looking update, 13 fused panel factorisation.  flops/bytes are the ALGORITHMIC
+ * left-looking update, 12 trailing left-looking update, 13 fused panel factorisation, 14 fused in-panel solve of the predict.  flops/bytes are the ALGORITHMIC
  * figures of DESIGN.md for the launches seen, not counter readings. */
 GPRC_API int gprc_prof_enable(int on);
 /* With the environment variable GPRC_PANEL_TRACE=<p> set, the factor role of the fused panel kernel of panel p leaves

@@ -196,3 +196,31 @@ def test_256x128_macro_tile_is_bit_identical():
         assert r.returncode == 0, r.stderr[-2000:]
         digests[(t256, solve)] = [ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0]
     assert len(set(digests.values())) == 1, digests
+
+
+def test_fused_in_panel_predict_solve_is_bit_identical():
+    """The predict's in-panel solve runs as one launch per panel (solve_panel_fused_kernel: a strip's four sub-steps back to
+    back); GPRC_SOLVE_PANEL=steps selects the seven-launch form.  Same tiles in the same order per strip: identical bits,
+    for the pointwise predict (with the fused sums of squares), the full covariance and GPC's latent predict."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import hashlib, numpy as np\n"
+        "from gprc_amd import GPR, GPC, cov_func, sqrexp\n"
+        "rng = np.random.default_rng(47)\n"
+        "X = rng.uniform(-1, 1, (3, 1900)); y = rng.normal(size=1900); Xs = rng.uniform(-1, 1, (3, 700))\n"
+        "g = GPR(X, y, 0.1, cov_func(sqrexp, l=0.7))\n"
+        "gc = GPC(X[:, :600], np.sign(X[0, :600] + 0.3 * X[1, :600]), cov_func(sqrexp, l=0.8), 1e-5)\n"
+        "parts = [g.predict(Xs), g.predict(Xs[:, :150], pointwise_var=False)[1], np.column_stack(gc.predict_latent(Xs))]\n"
+        "h = hashlib.sha256(); [h.update(np.ascontiguousarray(a).tobytes()) for a in parts]\n"
+        "print('DIGEST', h.hexdigest())\n") % (os.path.dirname(here), here)
+    digests = {}
+    for mode in ("fused", "steps"):
+        env = dict(os.environ, GPRC_SOLVE_PANEL=mode)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests[mode] = [ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0]
+    assert digests["fused"] == digests["steps"], digests
