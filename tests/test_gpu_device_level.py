@@ -213,7 +213,7 @@ def test_fused_in_panel_predict_solve_is_bit_identical():
         "rng = np.random.default_rng(47)\n"
         "X = rng.uniform(-1, 1, (3, 1900)); y = rng.normal(size=1900); Xs = rng.uniform(-1, 1, (3, 700))\n"
         "g = GPR(X, y, 0.1, cov_func(sqrexp, l=0.7))\n"
-        "gc = GPC(X[:, :600], np.sign(X[0, :600] + 0.3 * X[1, :600]), cov_func(sqrexp, l=0.8), 1e-5)\n"
+        "gc = GPC(X[:, :600], np.sign(X[0, :600] + 0.3 * X[1, :600]), cov_func(sqrexp, l=0.8), 1e-5, reference_stop=False)\n"
         "parts = [g.predict(Xs), g.predict(Xs[:, :150], pointwise_var=False)[1], np.column_stack(gc.predict_latent(Xs))]\n"
         "h = hashlib.sha256(); [h.update(np.ascontiguousarray(a).tobytes()) for a in parts]\n"
         "print('DIGEST', h.hexdigest())\n") % (os.path.dirname(here), here)
