@@ -124,28 +124,11 @@ __device__ __forceinline__ double gemv_group_partial(const double* Lr, int64_t l
   return (s0 + s1) + (s2 + s3);
 }
 
-// Touches (loads and discards) the operands the NEXT diagonal solve will need -- the lower blocks of the diagonal NB x NB
-// block of panel pn and its four block inverses, ~1.3 MB -- so that they sit in the Infinity Cache / an L2 when that
-// one-workgroup, latency-bound kernel runs (GPRC_TRSV_WARM=1: one extra workgroup riding on the wide product).
-__device__ __forceinline__ void trsv_warm_diag(const double* packed, const double* winv, int64_t n_pad, int pn, double* sink) {
-  const int64_t ld = panel_ld(n_pad, pn);
-  const double* pan = packed + panel_offset(n_pad, pn);
-  const double* W = winv + (int64_t)pn * TPP * 128 * 128;
-  double acc = 0.0;
-  for (int e = threadIdx.x; e < NB * (NB / 16); e += blockDim.x) {      // one 8-byte word per 128-byte line of the NB x NB block
-    const int c = e / (NB / 16), r = (e % (NB / 16)) * 16;
-    if (r + 15 >= c) acc += pan[r + (int64_t)c * ld];
-  }
-  for (int e = threadIdx.x; e < TPP * 128 * 128 / 16; e += blockDim.x) acc += W[(int64_t)e * 16];
-  if (acc == 1.2345e-300) sink[0] = acc;                                // never true: keeps the loads alive
-}
-
 // b[r] -= sum_c L[r, p*NB + c] * x_p[c] for the rows below panel p.  512 threads = 128 rows x 4 column groups.
-__global__ __launch_bounds__(512) void trsv_gemv_below(const double* packed, int64_t n_pad, int p, double* b, const double* winv_warm) {
+__global__ __launch_bounds__(512) void trsv_gemv_below(const double* packed, int64_t n_pad, int p, double* b) {
   __shared__ double xs[NB];
   __shared__ double red[4][128];
   const int t = threadIdx.x, i = t & 127, g = t >> 7;
-  if (winv_warm && blockIdx.x == gridDim.x - 1) { trsv_warm_diag(packed, winv_warm, n_pad, p + 1, &red[0][0]); return; }
   for (int c = t; c < NB; c += 512) xs[c] = b[(int64_t)p * NB + c];
   __syncthreads();
   const int64_t ld = panel_ld(n_pad, p);
@@ -230,10 +213,9 @@ __device__ __forceinline__ double gemvt_column_dot(const double* col, const doub
 }
 
 // z[q*NB + c] -= sum_r L[p*NB + r, q*NB + c] * x_p[r] for every earlier panel q < p.  Block = (q, 32 columns).
-__global__ __launch_bounds__(256) void trsv_gemvt_above(const double* packed, int64_t n_pad, int p, double* z, const double* winv_warm) {
+__global__ __launch_bounds__(256) void trsv_gemvt_above(const double* packed, int64_t n_pad, int p, double* z) {
   __shared__ double xs[NB];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  if (winv_warm && blockIdx.x == gridDim.x - 1) { trsv_warm_diag(packed, winv_warm, n_pad, p - 1, xs); return; }
   for (int c = t; c < NB; c += 256) xs[c] = z[(int64_t)p * NB + c];
   __syncthreads();
   const int q = blockIdx.x / (NB / 32), cg = blockIdx.x % (NB / 32);
@@ -709,15 +691,13 @@ int64_t rowreduce_splits(int64_t cols) { return (cols + RR_COLS - 1) / RR_COLS; 
 int launch_trsv_step(hipStream_t s, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose, int p) {
   const int P = (int)(n_pad / NB);
   if (p < 0 || p >= P) { set_error("trsv_step: panel out of range"); return GPRC_ERR_ARG; }
-  static const bool warm = [] { const char* e = std::getenv("GPRC_TRSV_WARM"); return e && std::atoi(e) == 1; }();
-  const double* ww = warm ? winv : nullptr;   // one extra workgroup per product: touches the next diagonal solve's operands
   if (!transpose) {
     hipLaunchKernelGGL(trsv_diag_fwd, dim3(1), dim3(1024), 0, s, packed, winv, n_pad, p, b);
     const int64_t below = n_pad - (int64_t)(p + 1) * NB;
-    if (below > 0) hipLaunchKernelGGL(trsv_gemv_below, dim3((unsigned)(below / 128 + (warm ? 1 : 0))), dim3(512), 0, s, packed, n_pad, p, b, ww);
+    if (below > 0) hipLaunchKernelGGL(trsv_gemv_below, dim3((unsigned)(below / 128)), dim3(512), 0, s, packed, n_pad, p, b);
   } else {
     hipLaunchKernelGGL(trsv_diag_bwd, dim3(1), dim3(1024), 0, s, packed, winv, n_pad, p, b);
-    if (p > 0) hipLaunchKernelGGL(trsv_gemvt_above, dim3((unsigned)(p * (NB / 32) + (warm ? 1 : 0))), dim3(256), 0, s, packed, n_pad, p, b, ww);
+    if (p > 0) hipLaunchKernelGGL(trsv_gemvt_above, dim3((unsigned)(p * (NB / 32))), dim3(256), 0, s, packed, n_pad, p, b);
   }
   GPRC_LAUNCH_CHECK();
   return 0;
