@@ -84,3 +84,36 @@ def test_call_shim_type_checks_against_the_real_header():
     native_r = open(os.path.join(ROOT, "gaussian-process-regression_amd", "r", "R", "native.R")).read()
     for name in re.findall(r"\.Call\((gprc_R_[a-zA-Z_]+)", native_r):     # every .Call target exists in the shim
         assert name in registered, name
+
+
+def test_native_r_is_lexically_well_formed():
+    """No R interpreter exists in the image, so r/R/native.R cannot even be parsed by R here.  This is the weakest useful
+    check: with strings and comments stripped, every bracket closes in order, and every function the file defines for the
+    R6 bodies / exports is present.  (The file stays UNVERIFIED against a live R: INTEGRATION.md.)"""
+    text = open(os.path.join(ROOT, "gaussian-process-regression_amd", "r", "R", "native.R")).read()
+    out, i, n = [], 0, len(text)
+    while i < n:                                   # strip comments and string literals (R: # to end of line; "..." and '...')
+        ch = text[i]
+        if ch == "#":
+            while i < n and text[i] != "\n":
+                i += 1
+        elif ch in "\"'":
+            q = ch
+            i += 1
+            while i < n and text[i] != q:
+                i += 2 if text[i] == "\\" else 1
+            i += 1
+        else:
+            out.append(ch)
+            i += 1
+    stack, pairs = [], {")": "(", "]": "[", "}": "{"}
+    for ch in "".join(out):
+        if ch in "([{":
+            stack.append(ch)
+        elif ch in pairs:
+            assert stack and stack.pop() == pairs[ch], "unbalanced bracket in native.R"
+    assert not stack, "unclosed bracket in native.R"
+    for name in ("cov_func", "covariance_matrix", ".gpr_initialize_native", ".gpr_predict_native", ".gpc_initialize_native",
+                 ".gpc_predict_class_native", ".dens_native", ".dens_deriv_native", "multivariate_normal", "combine_all",
+                 "gprc_native_available", ".gprc_devices"):
+        assert re.search(r"(?m)^" + re.escape(name) + r"\s*<-\s*function", text), name
