@@ -198,7 +198,8 @@ def test_kernel_scalar_methods():
     assert constant(x, y, c=4.0) == 4.0
 
 
-@pytest.mark.parametrize("n,d,ns", [(1, 1, 4), (127, 3, 129), (513, 2, 50), (1500, 8, 333)])
+@pytest.mark.parametrize("n,d,ns", [(1, 1, 4), (127, 3, 129), (513, 2, 50), (1500, 8, 333),
+                                    (512, 2, 128), (1024, 3, 127), (1025, 1, 129), (2049, 4, 257)])   # at / around whole panels: no padding, one padded row
 def test_gpr_against_oracle(n, d, ns):
     rng = np.random.default_rng(n)
     X = rng.uniform(-1, 1, (d, n))
