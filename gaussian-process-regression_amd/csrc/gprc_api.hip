@@ -392,6 +392,31 @@ int factor_all_lookahead(gprc_ctx* ctx, double* packed, int64_t n_pad, double* w
   return 0;
 }
 
+// Right-looking sweep with the FACTOR SERVICE (kernels_chol.hip): the critical roles of every panel run in ONE persistent
+// three-workgroup launch on a side stream, started per panel by the trailing update's own tiles; the caller's stream carries the
+// ordinary strips (one launch per panel) and the trailing updates.  Same tiles in the same order: bit-identical.
+int factor_all_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev) {
+  hipStream_t s = ctx->stream;
+  const int64_t P = n_pad / NB;
+  if (!ctx->side_stream) {
+    int lo = 0, hi = 0;
+    GPRC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    GPRC_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi));
+  }
+  hipStream_t side = ctx->side_stream;
+  DevMem sync;   // flags of every panel + the ready counters; goes back to the pool when every launch below has been ordered behind it
+  GPRC_TRY(sync.alloc((int64_t)(panel_service_sync_bytes(P) + 7) / 8));
+  GPRC_HIP(hipMemsetAsync(sync.p, 0, panel_service_sync_bytes(P), s));
+  GPRC_TRY(stream_after(ctx, side, s));                       // the fill, the caller's memset of info and the flag reset precede the service
+  GPRC_TRY(launch_panel_service(side, packed, n_pad, winv, info_dev, sync.p));
+  for (int64_t p = 0; p < P; ++p) {
+    GPRC_TRY(launch_panel_strips(s, packed, n_pad, p, winv, info_dev, sync.p));
+    if (p + 1 < P) GPRC_TRY(launch_trailing_update(s, packed, n_pad, p, p + 1, P, 1, panel_service_ready(sync.p, P, p + 1)));
+  }
+  GPRC_TRY(stream_after(ctx, s, side));
+  return 0;
+}
+
 int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev) {
   hipStream_t s = ctx->stream;
   const int64_t P = n_pad / NB;
@@ -402,6 +427,10 @@ int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv,
   // GPRC_LOOKAHEAD1=0/1 forces the choice; default: look-ahead up to n_pad = 24576
   static const int la_env = [] { const char* e = std::getenv("GPRC_LOOKAHEAD1"); return e ? std::atoi(e) : -1; }();
   static const bool panel_steps = [] { const char* e = std::getenv("GPRC_PANEL"); return e && std::strcmp(e, "steps") == 0; }();
+  // GPRC_SERVICE=0/1 forces the factor service off / on; default: on up to n_pad = 24576 (at most 188 strip workgroups can wait
+  // on it at once: the service's three workgroups always find their CUs)
+  static const int sv_env = [] { const char* e = std::getenv("GPRC_SERVICE"); return e ? std::atoi(e) : -1; }();
+  if (!mode && !panel_steps && P >= 2 && la_env < 0 && n_pad <= 24576 && sv_env != 0) return factor_all_service(ctx, packed, n_pad, winv, info_dev);
   if (!mode && !panel_steps && P >= 2 && (la_env == 1 || (la_env < 0 && n_pad <= 24576))) return factor_all_lookahead(ctx, packed, n_pad, winv, info_dev);
   for (int64_t g0 = 0; g0 < P;) {
     int64_t g1 = g0, tiles = 0;

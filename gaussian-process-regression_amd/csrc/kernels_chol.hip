@@ -658,8 +658,10 @@ __global__ __launch_bounds__(256, 2) void trsm_panel_kernel(double* X, int64_t l
 
 // Trailing update over the packed layout: for every target panel q in {q_begin, q_begin+stride, ..}
 // C_q -= L_p[rows of q] * L_p[rows of q's diagonal block]^T, lower tiles only.
+// ready (may be null): the lower tiles of the FIRST target panel's diagonal block count themselves into *ready, behind a release,
+// once their results are stored -- the factor service starts that panel's critical chain on it
 __global__ __launch_bounds__(256, 2) void trailing_kernel(double* packed, int64_t n_pad, int p, int q_begin, int q_stride,
-                                                          int n_targets, int ntiles) {
+                                                          int n_targets, int ntiles, int* ready) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int P = (int)(n_pad / NB);
   constexpr int DIAG_TILES = TPP * (TPP + 1) / 2;
@@ -687,6 +689,15 @@ __global__ __launch_bounds__(256, 2) void trailing_kernel(double* packed, int64_
     double* Cq = packed + panel_offset(n_pad, q);
     gemm_tile_128<false>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, Lp + (int64_t)tr * 128, ldp,
                          Lp + (int64_t)tc * 128, ldp, NB, smem);
+    if (ready && s == 0 && id < DIAG_TILES) {       // workgroup-uniform
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     __syncthreads();
   }
 }
@@ -835,9 +846,9 @@ __device__ __forceinline__ void panel_flag_wait(int* flag, PanelSync* sy, int* i
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
       __builtin_amdgcn_s_sleep(2);
       // exit condition every wave reaches (a producer that never publishes must not leave this workgroup spinning on the GPU
-      // for ever; ~2^25 polls is tens of seconds): give up, let the grid drain, and tell the host through the ONE word it always
-      // reads after a factorisation -- info = GPRC_INFO_WAIT_TIMEOUT (< 0; LAPACK infos are > 0)
-      if (++spins > (1 << 25)) {
+      // for ever; ~2^23 polls is several seconds, legitimate waits are below a millisecond): give up, let the grid drain, and tell
+      // the host through the ONE word it always reads after a factorisation -- info = GPRC_INFO_WAIT_TIMEOUT (< 0; LAPACK infos are > 0)
+      if (++spins > (1 << 23)) {
         __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
         break;
@@ -868,6 +879,68 @@ __device__ __forceinline__ void gemm_tile_shadow_barriers(int K) {
 
 // trace (may be null): the factor role's lane 0 leaves s_memrealtime stamps (100 MHz) of its stages there -- measurement only
 #define PANEL_STAMP(k) do { if (trace && t == 0) trace[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+
+// The factor role of one panel: 512 threads (8 waves), sm = PB_SMEM_DOUBLES doubles of LDS.
+__device__ __forceinline__ void panel_factor_role(double* sm, double* pan, int64_t ld, double* wp, int* info, int p, PanelSync* sy,
+                                                  unsigned long long* trace) {
+  const int t = threadIdx.x, team = t >> 8, tid = t & 255;
+  PANEL_STAMP(0);
+  for (int j = 0; j < TPP; ++j) {
+    potf2_blocked_body<8>(sm, pan + (int64_t)j * NBI + (int64_t)j * NBI * ld, ld, wp + (int64_t)j * NBI * NBI, info, p * NB + j * NBI);
+    PANEL_STAMP(1 + 6 * j);
+    panel_flag_publish(&sy->W[j]);               // (its vmcnt(0) + barrier also make L(j,j) / Winv_j visible to this workgroup's own DMA)
+    PANEL_STAMP(2 + 6 * j);
+    if (j + 1 == TPP) break;
+    // the two tiles the next diagonal block is waiting for, by team 0 (team 1 shadows the barriers)
+    double* Cn = pan + (int64_t)(j + 1) * NBI + (int64_t)j * NBI * ld;            // block (j+1, j)
+    double* Dn = pan + (int64_t)(j + 1) * NBI + (int64_t)(j + 1) * NBI * ld;      // block (j+1, j+1)
+    if (j > 0) panel_flag_wait(&sy->E[j + 1], sy, info);                          // their updates with the columns left of block j
+    PANEL_STAMP(3 + 6 * j);
+    if (team == 0) gemm_tile_128<true>(Cn, ld, Cn, ld, wp + (int64_t)j * NBI * NBI, 128, 128, sm, 0, 0, 0, nullptr, tid);
+    else gemm_tile_shadow_barriers(128);
+    PANEL_STAMP(4 + 6 * j);
+    panel_flag_publish(&sy->R[j + 1]);           // rows of strip j+1 left of its diagonal block are final
+    PANEL_STAMP(5 + 6 * j);
+    if (team == 0) gemm_tile_128<false>(Dn, ld, Cn, ld, Cn, ld, 128, sm, 0, 0, 0, nullptr, tid);
+    else gemm_tile_shadow_barriers(128);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                             // the updated block is reloaded by all 8 waves in potf2
+    PANEL_STAMP(6 + 6 * j);
+  }
+}
+
+// The role of strip s (128 rows of the panel) for ONE 4-wave team: tid = thread within the team, smem = the team's
+// G_SMEM_DOUBLES of LDS.  s >= TPP: an ordinary strip; s = 2, 3: a diagonal strip (blocks (s, 0..s-2), then the early part of
+// blocks (s, s-1) and (s, s), then E_s); s = 0, 1 have nothing to do.  Its workgroup barriers and flag waits are workgroup-wide:
+// teams sharing a workgroup must run strips of the same kind.
+__device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int64_t ld, double* wp, int* info, PanelSync* sy, int s, int tid) {
+  if (s < 2) return;
+  const double* Arow = pan + (int64_t)s * 128;     // my 128 rows of the panel
+  const int jlast = s < TPP ? s - 2 : TPP - 1;     // a diagonal strip solves blocks (s, 0..s-2) itself
+  for (int j = 0; j <= jlast; ++j) {
+    const int64_t cj = (int64_t)j * NBI;
+    double* C = pan + (int64_t)s * 128 + cj * ld;
+    __syncthreads();                               // the previous tile's LDS reads are over before this one's first DMA lands
+    if (j > 0) {
+      panel_flag_wait(&sy->R[j], sy, info);        // rows of strip j left of its diagonal block are final
+      gemm_tile_128<false>(C, ld, Arow, ld, pan + cj, ld, (int)cj, smem, 0, 0, 0, nullptr, tid);
+    }
+    panel_flag_wait(&sy->W[j], sy, info);
+    gemm_tile_128<true>(C, ld, C, ld, wp + (int64_t)j * NBI * NBI, 128, 128, smem, 0, 0, 0, nullptr, tid);
+  }
+  if (s < TPP) {                                   // diagonal strip: the early part of blocks (s, s-1) and (s, s): K = 128 (s-1)
+    const int64_t K = (int64_t)(s - 1) * NBI;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my own L(s, 0..s-2): every wave's stores, then the barrier
+    __syncthreads();
+    // the diagonal block first: it needs my own rows only, so it runs while strip s-1's rows are still on their way
+    gemm_tile_128<false>(pan + (int64_t)s * 128 + (int64_t)s * NBI * ld, ld, Arow, ld, Arow, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
+    __syncthreads();
+    panel_flag_wait(&sy->R[s - 1], sy, info);
+    gemm_tile_128<false>(pan + (int64_t)s * 128 + K * ld, ld, Arow, ld, pan + K, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
+    panel_flag_publish(&sy->E[s]);
+  }
+}
+
 __global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_t n_pad, int p, double* winv, int* info, PanelSync* sy,
                                                           unsigned long long* trace) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -881,69 +954,80 @@ __global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_
   double* wp = winv + (int64_t)p * TPP * NBI * NBI;
   const int S = (int)(ld / 128);
   const int team = t >> 8, tid = t & 255;
-
   if (id == 0) {                                   // ---- factor role: the critical chain
-    PANEL_STAMP(0);
-    for (int j = 0; j < TPP; ++j) {
-      potf2_blocked_body<8>(sm, pan + (int64_t)j * NBI + (int64_t)j * NBI * ld, ld, wp + (int64_t)j * NBI * NBI, info, p * NB + j * NBI);
-      PANEL_STAMP(1 + 6 * j);
-      panel_flag_publish(&sy->W[j]);               // (its vmcnt(0) + barrier also make L(j,j) / Winv_j visible to this workgroup's own DMA)
-      PANEL_STAMP(2 + 6 * j);
-      if (j + 1 == TPP) break;
-      // the two tiles the next diagonal block is waiting for, by team 0 (team 1 shadows the barriers)
-      double* Cn = pan + (int64_t)(j + 1) * NBI + (int64_t)j * NBI * ld;            // block (j+1, j)
-      double* Dn = pan + (int64_t)(j + 1) * NBI + (int64_t)(j + 1) * NBI * ld;      // block (j+1, j+1)
-      if (j > 0) panel_flag_wait(&sy->E[j + 1], sy, info);                                // their updates with the columns left of block j
-      PANEL_STAMP(3 + 6 * j);
-      if (team == 0) gemm_tile_128<true>(Cn, ld, Cn, ld, wp + (int64_t)j * NBI * NBI, 128, 128, sm, 0, 0, 0, nullptr, tid);
-      else gemm_tile_shadow_barriers(128);
-      PANEL_STAMP(4 + 6 * j);
-      panel_flag_publish(&sy->R[j + 1]);           // rows of strip j+1 left of its diagonal block are final
-      PANEL_STAMP(5 + 6 * j);
-      if (team == 0) gemm_tile_128<false>(Dn, ld, Cn, ld, Cn, ld, 128, sm, 0, 0, 0, nullptr, tid);
-      else gemm_tile_shadow_barriers(128);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                             // the updated block is reloaded by all 8 waves in potf2
-      PANEL_STAMP(6 + 6 * j);
-    }
+    panel_factor_role(sm, pan, ld, wp, info, p, sy, trace);
     return;
   }
-  // ---- strip roles
   int s;
   if (id <= TPP) {                                 // a diagonal strip: one team
     if (team == 1) return;
     s = id - 1;
-    if (s == 0) return;                            // block (0, 0) needs nothing but the factor role
   } else {
     s = TPP + 2 * (id - TPP - 1) + team;
     if (s >= S) return;                            // odd strip count: the last workgroup runs one team
   }
-  double* smem = sm + team * G_SMEM_DOUBLES;
-  const double* Arow = pan + (int64_t)s * 128;     // my 128 rows of the panel
-  const int jlast = s < TPP ? s - 2 : TPP - 1;     // a diagonal strip solves blocks (s, 0..s-2) itself
-  for (int j = 0; j <= jlast; ++j) {
-    const int64_t cj = (int64_t)j * NBI;
-    double* C = pan + (int64_t)s * 128 + cj * ld;
-    __syncthreads();                               // the previous tile's LDS reads are over before this one's first DMA lands
-    if (j > 0) {
-      panel_flag_wait(&sy->R[j], sy, info);              // rows of strip j left of its diagonal block are final
-      gemm_tile_128<false>(C, ld, Arow, ld, pan + cj, ld, (int)cj, smem, 0, 0, 0, nullptr, tid);
+  panel_strip_role(sm + team * G_SMEM_DOUBLES, pan, ld, wp, info, sy, s, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The factor SERVICE: the critical roles of every panel in one persistent launch (one-GPU right-looking sweep, n <= 24576).
+//
+// With one fused launch per panel the chain of panel p + 1 (330 us) starts only when the whole trailing update of panel p has
+// drained, and run beside that update (look-ahead streams) its workgroups queue for whole CUs behind the update's GEMM tiles
+// (0.41 -> 0.5..0.96 ms per panel).  Here three workgroups -- the factor role and the diagonal strips 2 and 3 -- are launched
+// ONCE per factorisation on a side stream and stay resident (3 of 256 CUs): they walk through the panels, each starting panel p
+// as soon as the ten lower tiles of its diagonal block have received panel p - 1 (the trailing update's tiles of that block
+// count themselves into ready[p] behind a release), and publish the same W / R / E flags as the fused kernel, per panel.
+// The main stream carries only throughput work: per panel one launch for the ordinary strips (panel_strips_kernel: they wait on
+// the service's flags, which are normally long set) and the trailing update.  The dependent chain of the whole factorisation
+// is then the service's 330 us per panel, hidden behind the updates wherever those are longer.  Same tiles, same order:
+// bit-identical.  No deadlock: the service is resident before anything that waits on it is launched (at most 188 strip
+// workgroups can spin, 3 CUs suffice for the service), and it waits only on kernels that precede, in stream order, every kernel
+// that waits on it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void panel_ready_wait(int* ctr, int need, PanelSync* sy, int* info) {   // the whole workgroup calls it
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1 << 22)) {   // bounded (see panel_flag_wait): seconds, where the longest legitimate wait -- one trailing update at n <= 24576 -- is ~10 ms
+        __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
+        break;
+      }
     }
-    panel_flag_wait(&sy->W[j], sy, info);
-    gemm_tile_128<true>(C, ld, C, ld, wp + (int64_t)j * NBI * NBI, 128, 128, smem, 0, 0, 0, nullptr, tid);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  if (s < TPP && s >= 2) {                         // diagonal strip: the early part of blocks (s, s-1) and (s, s): K = 128 (s-1)
-    const int64_t K = (int64_t)(s - 1) * NBI;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my own L(s, 0..s-2): every wave's stores, then the barrier
-    __syncthreads();
-    // the diagonal block first: it needs my own rows only, so it runs while strip s-1's rows are still on their way
-    // (measured: with the other order the factor role waited 10-12 us for E_3)
-    gemm_tile_128<false>(pan + (int64_t)s * 128 + (int64_t)s * NBI * ld, ld, Arow, ld, Arow, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
-    __syncthreads();
-    panel_flag_wait(&sy->R[s - 1], sy, info);
-    gemm_tile_128<false>(pan + (int64_t)s * 128 + K * ld, ld, Arow, ld, pan + K, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
-    panel_flag_publish(&sy->E[s]);
+  __syncthreads();
+}
+
+constexpr int PANEL_DIAG_TILES = TPP * (TPP + 1) / 2;
+
+__global__ __launch_bounds__(512) void panel_service_kernel(double* packed, int64_t n_pad, double* winv, int* info, PanelSync* sy_base,
+                                                            int* ready, int P) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int role = blockIdx.x;                     // 0: factor role; 1, 2: diagonal strips 2, 3
+  const int t = threadIdx.x, team = t >> 8, tid = t & 255;
+  if (role > 0 && team == 1) return;               // a diagonal strip is one 4-wave team
+  for (int p = 0; p < P; ++p) {
+    PanelSync* sy = sy_base + p;
+    if (p > 0) panel_ready_wait(&ready[p], PANEL_DIAG_TILES, sy, info);
+    const int64_t ld = panel_ld(n_pad, p);
+    double* pan = packed + panel_offset(n_pad, p);
+    double* wp = winv + (int64_t)p * TPP * NBI * NBI;
+    if (role == 0) panel_factor_role(sm, pan, ld, wp, info, p, sy, nullptr);
+    else panel_strip_role(sm, pan, ld, wp, info, sy, role + 1, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // LDS and this panel's stores are settled before the next panel's first DMA
   }
+}
+
+// the ordinary strips (s >= 4) of panel p, one 4-wave workgroup each, waiting on the service's flags
+__global__ __launch_bounds__(256, 2) void panel_strips_kernel(double* packed, int64_t n_pad, int p, double* winv, int* info, PanelSync* sy) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int64_t ld = panel_ld(n_pad, p);
+  panel_strip_role(smem, packed + panel_offset(n_pad, p), ld, winv + (int64_t)p * TPP * NBI * NBI, info, sy, TPP + (int)blockIdx.x, (int)threadIdx.x);
 }
 
 }  // namespace
@@ -995,6 +1079,43 @@ int launch_panel_fused(hipStream_t s, double* packed, int64_t n_pad, int64_t p, 
   return 0;
 }
 
+static int ensure_gemm_attrs();
+
+size_t panel_service_sync_bytes(int64_t P) { return (size_t)P * sizeof(PanelSync) + (size_t)P * sizeof(int) + 64; }
+
+// sync: panel_service_sync_bytes(P) bytes of device memory, zeroed by the caller (stream-ordered before this launch)
+int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync) {
+  static bool attr_set[MAX_DEVICES] = {};
+  const size_t smem = PB_SMEM_DOUBLES * sizeof(double);
+  int dev = 0;
+  GPRC_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEVICES || !attr_set[dev]) {
+    GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_service_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (dev >= 0 && dev < MAX_DEVICES) attr_set[dev] = true;
+  }
+  const int64_t P = n_pad / NB;
+  PanelSync* sy = reinterpret_cast<PanelSync*>(sync);
+  int* ready = reinterpret_cast<int*>(static_cast<char*>(sync) + (size_t)P * sizeof(PanelSync));
+  ProfScope ps(s, PK_PANEL_FUSED, 0.0, 0.0);
+  hipLaunchKernelGGL(panel_service_kernel, dim3(3), dim3(512), smem, s, packed, n_pad, winv, info_dev, sy, ready, (int)P);
+  GPRC_LAUNCH_CHECK();
+  return 0;
+}
+int* panel_service_ready(void* sync, int64_t P, int64_t p) { return reinterpret_cast<int*>(static_cast<char*>(sync) + (size_t)P * sizeof(PanelSync)) + p; }
+
+int launch_panel_strips(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync) {
+  const int64_t ld = panel_ld(n_pad, p), S = ld / 128;
+  if (S <= TPP) return 0;
+  GPRC_TRY(ensure_gemm_attrs());
+  double fl = 0.0;
+  for (int j = 0; j < TPP; ++j) fl += 2.0 * (double)(ld - NB) * NBI * (j * NBI) + (double)(ld - NB) * NBI * NBI;
+  ProfScope ps(s, PK_GEMM_INNER, fl, 8.0 * 2.0 * (double)(ld - NB) * NB);
+  hipLaunchKernelGGL(panel_strips_kernel, dim3((unsigned)(S - TPP)), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)p, winv,
+                     info_dev, reinterpret_cast<PanelSync*>(sync) + p);
+  GPRC_LAUNCH_CHECK();
+  return 0;
+}
+
 static int ensure_gemm_attrs() {
   static bool done[MAX_DEVICES] = {};  // per device, as above
   int dev = 0;
@@ -1009,6 +1130,7 @@ static int ensure_gemm_attrs() {
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_panel_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_panel_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_strips_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_left_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_range_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   if (dev >= 0 && dev < MAX_DEVICES) done[dev] = true;
@@ -1102,7 +1224,7 @@ int launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64
 }
 
 int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t p, int64_t q_begin, int64_t q_end,
-                           int64_t q_stride) {
+                           int64_t q_stride, int* ready) {
   const int64_t P = n_pad / NB;
   if (q_begin <= p || q_stride <= 0) { set_error("trailing_update: bad panel range"); return GPRC_ERR_ARG; }
   if (q_end > P) q_end = P;
@@ -1122,7 +1244,7 @@ int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t
   static const int pg = std::getenv("GPRC_PERSIST") ? std::atoi(std::getenv("GPRC_PERSIST")) : 0;
   const unsigned grid = (unsigned)((pg > 0 && tiles > pg) ? pg : tiles);
   hipLaunchKernelGGL(trailing_kernel, dim3(grid), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)p,
-                     (int)q_begin, (int)q_stride, (int)nt, (int)tiles);
+                     (int)q_begin, (int)q_stride, (int)nt, (int)tiles, ready);
   GPRC_LAUNCH_CHECK();
   return 0;
 }
