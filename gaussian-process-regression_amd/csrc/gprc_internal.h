@@ -101,7 +101,7 @@ int launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64
 // left-looking predict-solve step: vt[:, j NB:(j+G) NB] -= vt[:, 0:j NB] * L[j NB:(j+G) NB, 0:j NB]^T   (L packed)
 int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t j, int64_t G);
 int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t p, int64_t q_begin, int64_t q_end,
-                           int64_t q_stride, int* ready = nullptr);
+                           int64_t q_stride, int* ready = nullptr, int part = 0);
 // factor service (one-GPU right-looking sweep): the critical roles of all panels in one persistent launch + per-panel strips
 size_t panel_service_sync_bytes(int64_t P);
 int* panel_service_ready(void* sync, int64_t P, int64_t p);

@@ -660,13 +660,15 @@ __global__ __launch_bounds__(256, 2) void trsm_panel_kernel(double* X, int64_t l
 // C_q -= L_p[rows of q] * L_p[rows of q's diagonal block]^T, lower tiles only.
 // ready (may be null): the lower tiles of the FIRST target panel's diagonal block count themselves into *ready, behind a release,
 // once their results are stored -- the factor service starts that panel's critical chain on it
+// tile_first: the launch covers the logical tiles [tile_first, tile_first + ntiles) of the target list (the factor service runs the
+// ten diagonal-block tiles of the next panel as a launch of their own, ahead of the rest)
 __global__ __launch_bounds__(256, 2) void trailing_kernel(double* packed, int64_t n_pad, int p, int q_begin, int q_stride,
-                                                          int n_targets, int ntiles, int* ready) {
+                                                          int n_targets, int ntiles, int* ready, int tile_first) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int P = (int)(n_pad / NB);
   constexpr int DIAG_TILES = TPP * (TPP + 1) / 2;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {  // persistent, as gemm_nt_kernel
-    int id = (int)xcd_remap((unsigned)t, (unsigned)ntiles);
+    int id = (int)xcd_remap((unsigned)t, (unsigned)ntiles) + tile_first;
     // locate the target panel: panel q holds TPP*TPP*(P-q) - TPP*(TPP-1)/2 lower tiles
     int q = q_begin, s = 0;
     for (; s < n_targets; ++s, q += q_stride) {
@@ -1223,14 +1225,19 @@ int launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64
   return 0;
 }
 
+// part: 0 all tiles; 1 only the lower tiles of the first target's diagonal block; 2 everything but those
 int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t p, int64_t q_begin, int64_t q_end,
-                           int64_t q_stride, int* ready) {
+                           int64_t q_stride, int* ready, int part) {
   const int64_t P = n_pad / NB;
   if (q_begin <= p || q_stride <= 0) { set_error("trailing_update: bad panel range"); return GPRC_ERR_ARG; }
   if (q_end > P) q_end = P;
   int64_t tiles = 0, nt = 0;
   for (int64_t q = q_begin; q < q_end; q += q_stride) { tiles += (int64_t)TPP * TPP * (P - q) - TPP * (TPP - 1) / 2; ++nt; }
-  if (tiles == 0) return 0;
+  constexpr int64_t DIAG = TPP * (TPP + 1) / 2;
+  int64_t tile_first = 0;
+  if (part == 1) tiles = std::min<int64_t>(tiles, DIAG);
+  else if (part == 2) { tile_first = DIAG; tiles -= DIAG; }
+  if (tiles <= 0) return 0;
   GPRC_TRY(ensure_gemm_attrs());
   double fl = 0.0, by = 0.0;  // algorithmic: lower triangle of the 512-wide diagonal block + everything below it
   for (int64_t q = q_begin; q < q_end; q += q_stride) {
@@ -1239,12 +1246,18 @@ int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t
     fl += 2.0 * elems * NB;
     by += 8.0 * (2.0 * elems + rows * NB);
   }
+  if (part != 0) {   // the two parts of a split update share its algorithmic work in proportion to their tiles
+    int64_t all = 0;
+    for (int64_t q = q_begin; q < q_end; q += q_stride) all += (int64_t)TPP * TPP * (P - q) - TPP * (TPP - 1) / 2;
+    fl *= (double)tiles / (double)all;
+    by *= (double)tiles / (double)all;
+  }
   ProfScope ps(s, PK_TRAILING, fl, by);
 
   static const int pg = std::getenv("GPRC_PERSIST") ? std::atoi(std::getenv("GPRC_PERSIST")) : 0;
   const unsigned grid = (unsigned)((pg > 0 && tiles > pg) ? pg : tiles);
   hipLaunchKernelGGL(trailing_kernel, dim3(grid), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)p,
-                     (int)q_begin, (int)q_stride, (int)nt, (int)tiles, ready);
+                     (int)q_begin, (int)q_stride, (int)nt, (int)tiles, ready, (int)tile_first);
   GPRC_LAUNCH_CHECK();
   return 0;
 }
