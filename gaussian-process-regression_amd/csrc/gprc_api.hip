@@ -68,6 +68,8 @@ void prof_end(hipStream_t s, int kind, double flops, double bytes) {
 
 using namespace gprc;
 
+constexpr int SVC_TRACE_PANELS = 48;
+
 struct gprc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -78,6 +80,7 @@ struct gprc_ctx {
   // one-GPU look-ahead (factor_all_async): the panel chain runs on a high-priority side stream beside the trailing update
   hipStream_t side_stream = nullptr;
   hipStream_t upd_stream = nullptr;   // CU-masked stream of the bulk trailing updates while a look-ahead sweep runs (see factor_all_lookahead)
+  void* svc_trace = nullptr;          // GPRC_SERVICE_TRACE: 16 stamps x SVC_TRACE_PANELS of the last factor-service sweep (measurement)
   hipEvent_t ev_pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned ev_next = 0;
   double* scal_dev = nullptr;  // 8 doubles of scalar results
@@ -392,9 +395,10 @@ int factor_all_lookahead(gprc_ctx* ctx, double* packed, int64_t n_pad, double* w
   return 0;
 }
 
-// Right-looking sweep with the FACTOR SERVICE (kernels_chol.hip): the critical roles of every panel run in ONE persistent
-// three-workgroup launch on a side stream, started per panel by the trailing update's own tiles; the caller's stream carries the
-// ordinary strips (one launch per panel) and the trailing updates.  Same tiles in the same order: bit-identical.
+// Right-looking sweep with the FACTOR SERVICE (kernels_chol.hip): the whole dependent chain -- diagonal blocks, the strips around
+// them, the rows of the next diagonal block and that block's update -- runs in ONE persistent ten-workgroup launch on a side
+// stream; the caller's stream carries the ordinary strips and the rest of the trailing update, one launch each per panel, tied to
+// the service by counters.  Same tiles in the same k order: bit-identical.
 int factor_all_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev) {
   hipStream_t s = ctx->stream;
   const int64_t P = n_pad / NB;
@@ -407,15 +411,18 @@ int factor_all_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* win
   DevMem sync;   // flags of every panel + the ready counters; goes back to the pool when every launch below has been ordered behind it
   GPRC_TRY(sync.alloc((int64_t)(panel_service_sync_bytes(P) + 7) / 8));
   GPRC_HIP(hipMemsetAsync(sync.p, 0, panel_service_sync_bytes(P), s));
-  GPRC_TRY(stream_after(ctx, side, s));                       // the fill, the caller's memset of info and the flag reset precede the service
-  GPRC_TRY(launch_panel_service(side, packed, n_pad, winv, info_dev, sync.p));
-  for (int64_t p = 0; p < P; ++p) {
-    GPRC_TRY(launch_panel_strips(s, packed, n_pad, p, winv, info_dev, sync.p));
-    // one launch; its first ten tiles (the next panel's diagonal block) release the service for panel p + 1.  (Running those ten
-    // tiles as a launch of their own, ahead of the rest, measured slower: the GPU idles beside them -- C2 fit 10.1 -> 10.5 ms,
-    // C5 38.6 -> 40.2 ms per iteration.)
-    if (p + 1 < P) GPRC_TRY(launch_trailing_update(s, packed, n_pad, p, p + 1, P, 1, panel_service_ready(sync.p, P, p + 1)));
+  static const bool want_trace = std::getenv("GPRC_SERVICE_TRACE") != nullptr;
+  void* trace = nullptr;
+  if (want_trace && P <= SVC_TRACE_PANELS) {
+    if (!ctx->svc_trace) GPRC_HIP(hipMalloc(&ctx->svc_trace, SVC_TRACE_PANELS * 16 * sizeof(int64_t)));
+    GPRC_HIP(hipMemsetAsync(ctx->svc_trace, 0, SVC_TRACE_PANELS * 16 * sizeof(int64_t), s));
+    trace = ctx->svc_trace;
   }
+  GPRC_TRY(stream_after(ctx, side, s));                       // the fill, the caller's memset of info and the flag reset precede the service
+  GPRC_TRY(launch_panel_service(side, packed, n_pad, winv, info_dev, sync.p, trace));
+  GPRC_TRY(launch_service_gate(s, n_pad, info_dev, sync.p));  // nothing that waits on the service starts before the service is resident
+  GPRC_TRY(launch_panel_strips(s, packed, n_pad, 0, winv, info_dev, sync.p, trace));      // the later panels' strips ride in the update kernels
+  for (int64_t p = 0; p + 1 < P; ++p) GPRC_TRY(launch_trailing_service(s, packed, n_pad, p, winv, info_dev, sync.p, trace));
   GPRC_TRY(stream_after(ctx, s, side));
   return 0;
 }
@@ -430,8 +437,7 @@ int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv,
   // GPRC_LOOKAHEAD1=0/1 forces the choice; default: look-ahead up to n_pad = 24576
   static const int la_env = [] { const char* e = std::getenv("GPRC_LOOKAHEAD1"); return e ? std::atoi(e) : -1; }();
   static const bool panel_steps = [] { const char* e = std::getenv("GPRC_PANEL"); return e && std::strcmp(e, "steps") == 0; }();
-  // GPRC_SERVICE=0/1 forces the factor service off / on; default: on up to n_pad = 24576 (at most 188 strip workgroups can wait
-  // on it at once: the service's three workgroups always find their CUs)
+  // GPRC_SERVICE=0 turns the factor service off; it runs up to n_pad = 24576 (beyond that the grouped left-looking schedule wins)
   static const int sv_env = [] { const char* e = std::getenv("GPRC_SERVICE"); return e ? std::atoi(e) : -1; }();
   if (!mode && !panel_steps && P >= 2 && la_env < 0 && n_pad <= 24576 && sv_env != 0) return factor_all_service(ctx, packed, n_pad, winv, info_dev);
   if (!mode && !panel_steps && P >= 2 && (la_env == 1 || (la_env < 0 && n_pad <= 24576))) return factor_all_lookahead(ctx, packed, n_pad, winv, info_dev);
@@ -763,6 +769,7 @@ int gprc_ctx_destroy(gprc_ctx* ctx) {
   if (ctx->info_dev) (void)hipFree(ctx->info_dev);
   if (ctx->scal_dev) (void)hipFree(ctx->scal_dev);
   if (ctx->sync_dev) (void)hipFree(ctx->sync_dev);
+  if (ctx->svc_trace) (void)hipFree(ctx->svc_trace);
   if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
   if (ctx->upd_stream) { (void)hipStreamSynchronize(ctx->upd_stream); (void)hipStreamDestroy(ctx->upd_stream); }
   for (hipEvent_t ev : ctx->ev_pool)
@@ -1368,6 +1375,15 @@ int gprc_prof_panel_trace(gprc_ctx* ctx, int side, int64_t* ticks_out, int n) {
   if (!ticks_out || n < 1 || n > 24) { set_error("prof_panel_trace: 1..24 stamps"); return GPRC_ERR_ARG; }
   GPRC_HIP(hipDeviceSynchronize());
   GPRC_HIP(hipMemcpy(ticks_out, static_cast<char*>(ctx->sync_dev) + (side ? 256 : 0) + 64, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int gprc_prof_service_trace(gprc_ctx* ctx, int64_t* ticks_out, int panels) {
+  GPRC_TRY(use_device(ctx));
+  if (!ticks_out || panels < 1 || panels > SVC_TRACE_PANELS) { set_error("prof_service_trace: 1..48 panels"); return GPRC_ERR_ARG; }
+  if (!ctx->svc_trace) { set_error("prof_service_trace: no traced sweep on this context (set GPRC_SERVICE_TRACE before the first call)"); return GPRC_ERR_ARG; }
+  GPRC_HIP(hipDeviceSynchronize());
+  GPRC_HIP(hipMemcpy(ticks_out, ctx->svc_trace, sizeof(int64_t) * 16 * (size_t)panels, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -101,12 +101,14 @@ int launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64
 // left-looking predict-solve step: vt[:, j NB:(j+G) NB] -= vt[:, 0:j NB] * L[j NB:(j+G) NB, 0:j NB]^T   (L packed)
 int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t j, int64_t G);
 int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t p, int64_t q_begin, int64_t q_end,
-                           int64_t q_stride, int* ready = nullptr, int part = 0);
-// factor service (one-GPU right-looking sweep): the critical roles of all panels in one persistent launch + per-panel strips
+                           int64_t q_stride);
+// factor service (one-GPU right-looking sweep): the dependent chain of all panels in one persistent launch (side stream) + per panel
+// the ordinary strips and the trailing update without the next diagonal block (caller's stream)
 size_t panel_service_sync_bytes(int64_t P);
-int* panel_service_ready(void* sync, int64_t P, int64_t p);
-int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync);
-int launch_panel_strips(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync);
+int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync, void* trace);
+int launch_service_gate(hipStream_t s, int64_t n_pad, int* info_dev, void* sync);
+int launch_panel_strips(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync, void* trace);
+int launch_trailing_service(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync, void* trace);
 
 // ---- launchers (kernels_vec.hip) ---------------------------------------------------------------
 int launch_trailing_left(hipStream_t s, double* packed, int64_t n_pad, int64_t q_begin, int64_t q_end);

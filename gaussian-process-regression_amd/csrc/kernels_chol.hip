@@ -658,17 +658,13 @@ __global__ __launch_bounds__(256, 2) void trsm_panel_kernel(double* X, int64_t l
 
 // Trailing update over the packed layout: for every target panel q in {q_begin, q_begin+stride, ..}
 // C_q -= L_p[rows of q] * L_p[rows of q's diagonal block]^T, lower tiles only.
-// ready (may be null): the lower tiles of the FIRST target panel's diagonal block count themselves into *ready, behind a release,
-// once their results are stored -- the factor service starts that panel's critical chain on it
-// tile_first: the launch covers the logical tiles [tile_first, tile_first + ntiles) of the target list (the factor service runs the
-// ten diagonal-block tiles of the next panel as a launch of their own, ahead of the rest)
 __global__ __launch_bounds__(256, 2) void trailing_kernel(double* packed, int64_t n_pad, int p, int q_begin, int q_stride,
-                                                          int n_targets, int ntiles, int* ready, int tile_first) {
+                                                          int n_targets, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int P = (int)(n_pad / NB);
   constexpr int DIAG_TILES = TPP * (TPP + 1) / 2;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {  // persistent, as gemm_nt_kernel
-    int id = (int)xcd_remap((unsigned)t, (unsigned)ntiles) + tile_first;
+    int id = (int)xcd_remap((unsigned)t, (unsigned)ntiles);
     // locate the target panel: panel q holds TPP*TPP*(P-q) - TPP*(TPP-1)/2 lower tiles
     int q = q_begin, s = 0;
     for (; s < n_targets; ++s, q += q_stride) {
@@ -691,15 +687,6 @@ __global__ __launch_bounds__(256, 2) void trailing_kernel(double* packed, int64_
     double* Cq = packed + panel_offset(n_pad, q);
     gemm_tile_128<false>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, Lp + (int64_t)tr * 128, ldp,
                          Lp + (int64_t)tc * 128, ldp, NB, smem);
-    if (ready && s == 0 && id < DIAG_TILES) {       // workgroup-uniform
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
     __syncthreads();
   }
 }
@@ -839,7 +826,9 @@ __global__ __launch_bounds__(256, 2) void trailing_range_kernel(double* packed, 
 // barrier, one lane's agent release fence + vmcnt(0), relaxed agent store of the flag; one lane polls with relaxed agent
 // loads, agent acquire fence + vmcnt(0), workgroup barrier, plain / LDS-DMA loads).
 // ------------------------------------------------------------------------------------------------
-struct PanelSync { int ticket; int failed; int W[4]; int E[4]; int R[4]; int pad[2]; };   // 16 ints, zeroed before the launch
+struct PanelSync { int ticket; int failed; int W[4]; int E[4]; int R[4]; int LA; int pad; };   // 16 ints, zeroed before the launch
+// (factor service only -- LA: finished sub-steps of the four look-ahead strips, 16 when rows [NB, 2 NB) of the panel are final;
+//  E[0], E[1]: blocks (s, j <= s-2) the diagonal strips s = 2, 3 have finished)
 
 __device__ __forceinline__ void panel_flag_wait(int* flag, PanelSync* sy, int* info) {   // the whole workgroup calls it
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own stores: its team-mates re-read them after the barrier
@@ -869,6 +858,34 @@ __device__ __forceinline__ void panel_flag_publish(int* flag) {               //
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__device__ __forceinline__ void panel_ready_wait(int* ctr, int need, PanelSync* sy, int* info) {   // the whole workgroup calls it
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 22)) {   // bounded (see panel_flag_wait): seconds, where the longest legitimate wait -- one trailing update at n <= 24576 -- is ~10 ms
+        __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void panel_count_publish(int* ctr, int add) {      // the whole workgroup calls it
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(ctr, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -915,7 +932,12 @@ __device__ __forceinline__ void panel_factor_role(double* sm, double* pan, int64
 // G_SMEM_DOUBLES of LDS.  s >= TPP: an ordinary strip; s = 2, 3: a diagonal strip (blocks (s, 0..s-2), then the early part of
 // blocks (s, s-1) and (s, s), then E_s); s = 0, 1 have nothing to do.  Its workgroup barriers and flag waits are workgroup-wide:
 // teams sharing a workgroup must run strips of the same kind.
-__device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int64_t ld, double* wp, int* info, PanelSync* sy, int s, int tid) {
+// progress (may be null; factor service): after every finished block (s, j) of the j loop the workgroup adds `teams` to it behind a
+// release.  early (may be null; factor service: the progress counters of the diagonal strips 2 and 3, early[0] / early[1]): an
+// ordinary strip then applies the k-chunks 0..j-2 of the update of block (s, j) as soon as L(j, 0..j-2) is final -- long before R_j --
+// and only the last chunk (columns of block j-1) after R_j: the same products in the same order, continued through memory.
+__device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int64_t ld, double* wp, int* info, PanelSync* sy, int s, int tid,
+                                                 int* progress = nullptr, int teams = 1, int* early = nullptr) {
   if (s < 2) return;
   const double* Arow = pan + (int64_t)s * 128;     // my 128 rows of the panel
   const int jlast = s < TPP ? s - 2 : TPP - 1;     // a diagonal strip solves blocks (s, 0..s-2) itself
@@ -924,11 +946,20 @@ __device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int6
     double* C = pan + (int64_t)s * 128 + cj * ld;
     __syncthreads();                               // the previous tile's LDS reads are over before this one's first DMA lands
     if (j > 0) {
-      panel_flag_wait(&sy->R[j], sy, info);        // rows of strip j left of its diagonal block are final
-      gemm_tile_128<false>(C, ld, Arow, ld, pan + cj, ld, (int)cj, smem, 0, 0, 0, nullptr, tid);
+      if (early && j >= 2) {
+        const int64_t ke = (int64_t)(j - 1) * NBI;
+        panel_ready_wait(&early[j - 2], j - 1, sy, info);   // L(j, 0..j-2) final
+        gemm_tile_128<false>(C, ld, Arow, ld, pan + cj, ld, (int)ke, smem, 0, 0, 0, nullptr, tid);
+        panel_flag_wait(&sy->R[j], sy, info);      // (its vmcnt(0) + barrier: the block is reloaded as the next call's C)
+        gemm_tile_128<false>(C, ld, Arow + ke * ld, ld, pan + cj + ke * ld, ld, 128, smem, 0, 0, 0, nullptr, tid);
+      } else {
+        panel_flag_wait(&sy->R[j], sy, info);      // rows of strip j left of its diagonal block are final
+        gemm_tile_128<false>(C, ld, Arow, ld, pan + cj, ld, (int)cj, smem, 0, 0, 0, nullptr, tid);
+      }
     }
     panel_flag_wait(&sy->W[j], sy, info);
     gemm_tile_128<true>(C, ld, C, ld, wp + (int64_t)j * NBI * NBI, 128, 128, smem, 0, 0, 0, nullptr, tid);
+    if (progress) panel_count_publish(progress, teams);
   }
   if (s < TPP) {                                   // diagonal strip: the early part of blocks (s, s-1) and (s, s): K = 128 (s-1)
     const int64_t K = (int64_t)(s - 1) * NBI;
@@ -972,64 +1003,209 @@ __global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_
 }
 
 // ------------------------------------------------------------------------------------------------
-// The factor SERVICE: the critical roles of every panel in one persistent launch (one-GPU right-looking sweep, n <= 24576).
+// The factor SERVICE: the whole dependent chain of a factorisation in one persistent launch (one-GPU right-looking sweep,
+// n <= 24576).
 //
-// With one fused launch per panel the chain of panel p + 1 (330 us) starts only when the whole trailing update of panel p has
-// drained, and run beside that update (look-ahead streams) its workgroups queue for whole CUs behind the update's GEMM tiles
-// (0.41 -> 0.5..0.96 ms per panel).  Here three workgroups -- the factor role and the diagonal strips 2 and 3 -- are launched
-// ONCE per factorisation on a side stream and stay resident (3 of 256 CUs): they walk through the panels, each starting panel p
-// as soon as the ten lower tiles of its diagonal block have received panel p - 1 (the trailing update's tiles of that block
-// count themselves into ready[p] behind a release), and publish the same W / R / E flags as the fused kernel, per panel.
-// The main stream carries only throughput work: per panel one launch for the ordinary strips (panel_strips_kernel: they wait on
-// the service's flags, which are normally long set) and the trailing update.  The dependent chain of the whole factorisation
-// is then the service's 330 us per panel, hidden behind the updates wherever those are longer.  Same tiles, same order:
-// bit-identical.  No deadlock: the service is resident before anything that waits on it is launched (at most 188 strip
-// workgroups can spin, 3 CUs suffice for the service), and it waits only on kernels that precede, in stream order, every kernel
-// that waits on it.
+// With one fused launch per panel the chain of panel p + 1 (330 us) starts only when the trailing update of panel p has drained,
+// and run beside that update on a second stream its workgroups queue for whole CUs behind the update's GEMM tiles.  Here 17
+// workgroups are launched ONCE per factorisation on a side stream and stay resident (17 of 256 CUs); they walk through the panels:
+//   role 0        the factor role of the fused kernel (diagonal blocks + the two tiles each next one waits for)
+//   roles 1, 2    the diagonal strips 2 and 3 (they also count their finished blocks (s, j <= s-2) into E[0] / E[1])
+//   roles 3..6    LOOK-AHEAD strips 4..7: the rows of panel p that are the rows of the NEXT diagonal block; after every finished
+//                 block (s, j) they count themselves into LA
+//   roles 7..16   the ten lower tiles of the next diagonal block: as soon as the look-ahead strips have finished sub-step j
+//                 (LA >= 4 (j + 1)), D(a, b) -= L(4+a, j) L(4+b, j)^T -- the K = 512 update of that tile in its four k-chunks, in
+//                 order, continuing one accumulator chain through memory -- and after chunk 3 they count themselves into
+//                 ready[p + 1], on which roles 0..2 start panel p + 1.
+// (One 4-wave team per CU: two teams sharing a CU ran a K = 128 tile in ~39 us instead of ~20, and those tiles are the path
+// between two panels' chains.)  So the distance between two chains is one 128-column solve + one K = 128 tile, with no kernel
+// launch, no drained GPU and no contended CU on it.  The caller's stream carries only throughput work, one launch per panel
+// (trailing_service_kernel): the trailing update of panel p WITHOUT the next diagonal block, and the ordinary strips (>= 8) of panel
+// p + 1, which wait on the service's W / R flags.  That kernel is tied in by counters: its tiles of the next panel's rows 4..7 count
+// into ready_la[p + 1] (the look-ahead strips of panel p + 1 wait for 16), its tiles of the diagonal block after the next count into
+// ready_d2[p + 2] (roles 7..16 wait for 10 before they add panel p + 1's part: k ascending, as in the launch-per-panel form), and its
+// tiles of the next panel's column wait for LA = 16 of panel p (their B operand is the look-ahead strips' result).  Same tiles, same
+// k order: bit-identical.
+// No deadlock: main-stream kernels of panel p wait only on service flags of panel p; the service waits, for panel p, only on the
+// update of panel p - 1, which waits only on service flags of panel p - 1; and nothing that waits on the service is launched before
+// the service is resident (service_gate_kernel, the first kernel on the caller's stream).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void panel_ready_wait(int* ctr, int need, PanelSync* sy, int* info) {   // the whole workgroup calls it
-  if (threadIdx.x == 0) {
-    int spins = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1 << 22)) {   // bounded (see panel_flag_wait): seconds, where the longest legitimate wait -- one trailing update at n <= 24576 -- is ~10 ms
-        __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
-        break;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+constexpr int PANEL_DIAG_TILES = TPP * (TPP + 1) / 2;
+constexpr int PANEL_LA_TILES = TPP * TPP;             // tiles of a panel's rows [NB, 2 NB)
+constexpr int SERVICE_LA0 = 3;                                   // first look-ahead strip role (one 4-wave team per workgroup)
+constexpr int SERVICE_D0 = SERVICE_LA0 + TPP;                    // first next-diagonal-block role (one tile per workgroup)
+constexpr int SERVICE_WGS = SERVICE_D0 + PANEL_DIAG_TILES;
+
+// One team's share of the next diagonal block: lower tile `idx` (0..9: (0,0) (1,0) (1,1) (2,0) ...) of the block, in four k-chunks.
+__device__ __forceinline__ void panel_next_diag_role(double* smem, const double* pan, int64_t ld, double* Dn, int64_t ldn, int* info,
+                                                     PanelSync* sy, int idx, int tid, unsigned long long* stamp) {
+  int tr = 0;
+  while ((tr + 1) * (tr + 2) / 2 <= idx) ++tr;
+  const int tc = idx - tr * (tr + 1) / 2;
+  double* C = Dn + (int64_t)tr * 128 + (int64_t)tc * 128 * ldn;
+  for (int j = 0; j < TPP; ++j) {
+    panel_ready_wait(&sy->LA, TPP * (j + 1), sy, info);
+    if (stamp && j == TPP - 1 && threadIdx.x == 0) *stamp = __builtin_amdgcn_s_memrealtime();
+    gemm_tile_128<false>(C, ldn, pan + (int64_t)(TPP + tr) * 128 + (int64_t)j * NBI * ld, ld, pan + (int64_t)(TPP + tc) * 128 + (int64_t)j * NBI * ld, ld,
+                         128, smem, 0, 0, 0, nullptr, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile is reloaded as the next chunk's C
+    __syncthreads();
   }
-  __syncthreads();
 }
 
-constexpr int PANEL_DIAG_TILES = TPP * (TPP + 1) / 2;
+// ready: three counters per panel -- ready[p]: lower tiles of diagonal block p complete (10); ready[P + p]: tiles of panel p's rows
+// [NB, 2 NB) that have received panel p - 1 (16); ready[2 P + p]: lower tiles of diagonal block p that have received panel p - 2 (10)
+// trace (may be null; GPRC_SERVICE_TRACE): 16 s_memrealtime stamps per panel, see gprc_prof_service_trace -- measurement only
+#define SERVICE_STAMP(p, k) do { if (trace && (threadIdx.x & 255) == 0) trace[16 * (p) + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 __global__ __launch_bounds__(512) void panel_service_kernel(double* packed, int64_t n_pad, double* winv, int* info, PanelSync* sy_base,
-                                                            int* ready, int P) {
+                                                            int* ready, int P, unsigned long long* trace) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int role = blockIdx.x;                     // 0: factor role; 1, 2: diagonal strips 2, 3
+  const int role = blockIdx.x;
   const int t = threadIdx.x, team = t >> 8, tid = t & 255;
-  if (role > 0 && team == 1) return;               // a diagonal strip is one 4-wave team
+  if (t == 0) __hip_atomic_fetch_add(&ready[3 * P], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident: see service_gate_kernel
+  if (role >= 1 && team == 1) return;                // every role but the factor role is one 4-wave team
   for (int p = 0; p < P; ++p) {
     PanelSync* sy = sy_base + p;
-    if (p > 0) panel_ready_wait(&ready[p], PANEL_DIAG_TILES, sy, info);
     const int64_t ld = panel_ld(n_pad, p);
     double* pan = packed + panel_offset(n_pad, p);
     double* wp = winv + (int64_t)p * TPP * NBI * NBI;
-    if (role == 0) panel_factor_role(sm, pan, ld, wp, info, p, sy, nullptr);
-    else panel_strip_role(sm, pan, ld, wp, info, sy, role + 1, tid);
+    if (role <= 2) {
+      if (role == 0) SERVICE_STAMP(p, 14);
+      if (p > 0) panel_ready_wait(&ready[p], PANEL_DIAG_TILES, sy, info);
+      if (role == 0) SERVICE_STAMP(p, 0);
+      if (role == 0) panel_factor_role(sm, pan, ld, wp, info, p, sy, nullptr);
+      else panel_strip_role(sm, pan, ld, wp, info, sy, role + 1, tid, &sy->E[role - 1], 1);
+      if (role == 0) SERVICE_STAMP(p, 1);
+    } else if (p + 1 < P) {
+      if (role < SERVICE_D0) {
+        if (p > 0) panel_ready_wait(&ready[P + p], PANEL_LA_TILES, sy, info);
+        if (role == SERVICE_LA0) SERVICE_STAMP(p, 2);
+        panel_strip_role(sm, pan, ld, wp, info, sy, TPP + (role - SERVICE_LA0), tid, &sy->LA, 1, sy->E);
+        if (role == SERVICE_LA0) SERVICE_STAMP(p, 3);
+      } else {
+        if (p > 0) panel_ready_wait(&ready[2 * P + p + 1], PANEL_DIAG_TILES, sy, info);
+        if (role == SERVICE_D0) SERVICE_STAMP(p, 4);
+        panel_next_diag_role(sm, pan, ld, packed + panel_offset(n_pad, p + 1), panel_ld(n_pad, p + 1), info, sy, role - SERVICE_D0, tid,
+                             (role == SERVICE_D0 && trace) ? trace + 16 * p + 5 : nullptr);
+        panel_count_publish(&ready[p + 1], 1);
+        if (role == SERVICE_WGS - 1) SERVICE_STAMP(p, 6);
+      }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                               // LDS and this panel's stores are settled before the next panel's first DMA
   }
 }
 
-// the ordinary strips (s >= 4) of panel p, one 4-wave workgroup each, waiting on the service's flags
-__global__ __launch_bounds__(256, 2) void panel_strips_kernel(double* packed, int64_t n_pad, int p, double* winv, int* info, PanelSync* sy) {
+// First kernel of the caller's stream: one wave that returns once every service workgroup is resident.  Whatever waits on the
+// service is ordered behind it, so a GPU full of waiting workgroups can never keep the service out.
+__global__ void service_gate_kernel(int* alive, int need, int* info) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(alive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1 << 22)) { atomicExch(info, GPRC_INFO_WAIT_TIMEOUT); break; }
+    }
+  }
+}
+
+// the ordinary strips (s >= 8) of panel p, one 4-wave workgroup each, waiting on the service's flags
+__global__ __launch_bounds__(256, 2) void panel_strips_kernel(double* packed, int64_t n_pad, int p, double* winv, int* info, PanelSync* sy,
+                                                              unsigned long long* trace) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int64_t ld = panel_ld(n_pad, p);
-  panel_strip_role(smem, packed + panel_offset(n_pad, p), ld, winv + (int64_t)p * TPP * NBI * NBI, info, sy, TPP + (int)blockIdx.x, (int)threadIdx.x);
+  if (blockIdx.x == 0) SERVICE_STAMP(p, 7);
+  panel_strip_role(smem, packed + panel_offset(n_pad, p), ld, winv + (int64_t)p * TPP * NBI * NBI, info, sy, 2 * TPP + (int)blockIdx.x, (int)threadIdx.x,
+                   nullptr, 1, sy->E);
+  if (blockIdx.x == 0) SERVICE_STAMP(p, 8);
+}
+
+// The caller's-stream kernel of panel p under the factor service: the trailing update of panel p -- every lower tile of the panels
+// behind p EXCEPT the next diagonal block (the service's roles 5..9 own it) -- AND the ordinary strips of panel p + 1, which so run
+// beside the bulk of the update instead of as a phase of their own (190 us per panel with the GPU two thirds empty).
+// Roles are dealt by a ticket counter in START order:
+//   tickets [0, n_first)                    the tiles of panel p + 1's own column, rows [NB, 2 NB) first: those 16 count into
+//                                           ready_la (the service's look-ahead strips of panel p + 1 wait for them), the others into
+//                                           rowcnt[their 128-row strip]; all of them first wait until the look-ahead strips of
+//                                           panel p are final (sy->LA = 16: their B operand)
+//   tickets [n_first, n_first + nstrips)    strip 8 + i of panel p + 1: waits for its four tiles (rowcnt = 4), then the strip role on
+//                                           the service's W / R flags of panel p + 1
+//   the rest                                all other tiles (XCD-contiguous ranges), the diagonal block of panel p + 2 first (-> ready_d2)
+// A strip workgroup can only be running when every ticket before it has started, so the tiles it waits for are running or done,
+// and those wait only on the service: no deadlock whatever the dispatch order.
+__global__ __launch_bounds__(256, 2) void trailing_service_kernel(double* packed, int64_t n_pad, int p, int ntiles, int nstrips, PanelSync* sy_base,
+                                                                  int* ready, int* rowcnt, double* winv, int* info, unsigned long long* trace) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ int sh_ticket;
+  const int P = (int)(n_pad / NB);
+  constexpr int DIAG = PANEL_DIAG_TILES;
+  PanelSync* sy = sy_base + p;
+  const int T0 = TPP * TPP * (P - p - 1) - TPP * (TPP - 1) / 2;   // tiles of panel p + 1 (>= DIAG + LAT: there are >= 2 targets)
+  const int n_first = T0 - DIAG;
+  // Only the first `base` workgroups (the waiting roles and what they wait for) take tickets; the rest map block id -> tile directly,
+  // so that block id mod 8 -- the XCD -- still selects a contiguous range of tiles (ticket order would scatter an XCD's tiles and
+  // with them the operand strips its L2 serves: measured -12 % on the update).
+  const int base = (n_first + nstrips + 7) & ~7;
+  int t;
+  if ((int)blockIdx.x < base) {
+    if (threadIdx.x == 0) sh_ticket = atomicAdd(&sy->ticket, 1);
+    __syncthreads();
+    t = sh_ticket;
+    if (t >= n_first + nstrips) return;
+  } else {
+    t = n_first + nstrips + ((int)blockIdx.x - base);
+  }
+  if (t == 0) SERVICE_STAMP(p, 9);
+  int s, local;                                                     // target index behind p + 1, tile index in that panel's list
+  bool sig_d2 = false;
+  if (t < n_first) { s = 0; local = DIAG + t; }
+  else if (t < n_first + nstrips) {                                 // ---- an ordinary strip of panel p + 1
+    const int q = p + 1, strip = 2 * TPP + (t - n_first);
+    if (strip == 2 * TPP) SERVICE_STAMP(q, 7);
+    panel_ready_wait(&rowcnt[(int64_t)q * TPP * P + strip], TPP, sy_base + q, info);
+    panel_strip_role(smem, packed + panel_offset(n_pad, q), panel_ld(n_pad, q), winv + (int64_t)q * TPP * NBI * NBI, info, sy_base + q, strip, (int)threadIdx.x,
+                     nullptr, 1, sy_base[q].E);
+    if (strip == 2 * TPP) SERVICE_STAMP(q, 8);
+    return;
+  } else {
+    const int nrest = ntiles - n_first;
+    int id = (int)xcd_remap((unsigned)(t - n_first - nstrips), (unsigned)nrest);
+    if (id == nrest - 1) SERVICE_STAMP(p, 13);
+    const int T1 = T0 - TPP * TPP;
+    if (id < DIAG) { s = 1; local = id; sig_d2 = true; }
+    else if (id < T1) { s = 1; local = id; }
+    else {
+      id -= T1;
+      s = 2;
+      for (;; ++s) {
+        if (p + 1 + s >= P) return;
+        const int tq = TPP * TPP * (P - p - 1 - s) - TPP * (TPP - 1) / 2;
+        if (id < tq) break;
+        id -= tq;
+      }
+      local = id;
+    }
+  }
+  const int q = p + 1 + s;
+  int tr, tc;
+  if (local < DIAG) {
+    tr = 0;
+    while ((tr + 1) * (tr + 2) / 2 <= local) ++tr;
+    tc = local - tr * (tr + 1) / 2;
+  } else {
+    tr = TPP + (local - DIAG) / TPP;
+    tc = (local - DIAG) % TPP;
+  }
+  if (s == 0) panel_ready_wait(&sy->LA, TPP * TPP, sy, info);
+  if (t == 0) SERVICE_STAMP(p, 10);
+  const int64_t ldp = panel_ld(n_pad, p), ldq = panel_ld(n_pad, q);
+  const double* Lp = packed + panel_offset(n_pad, p) + (int64_t)(q - p) * NB;  // row q*NB of panel p
+  double* Cq = packed + panel_offset(n_pad, q);
+  gemm_tile_128<false>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, Lp + (int64_t)tr * 128, ldp, Lp + (int64_t)tc * 128, ldp, NB, smem);
+  if (s == 0) panel_count_publish(tr < 2 * TPP ? &ready[P + q] : &rowcnt[(int64_t)q * TPP * P + tr], 1);
+  else if (sig_d2) panel_count_publish(&ready[2 * P + q], 1);
+  if (t == 0) SERVICE_STAMP(p, 11);
+  if (sig_d2 && local == 0) SERVICE_STAMP(p, 12);
 }
 
 }  // namespace
@@ -1083,10 +1259,12 @@ int launch_panel_fused(hipStream_t s, double* packed, int64_t n_pad, int64_t p, 
 
 static int ensure_gemm_attrs();
 
-size_t panel_service_sync_bytes(int64_t P) { return (size_t)P * sizeof(PanelSync) + (size_t)P * sizeof(int) + 64; }
+// flags of every panel | ready, ready_la, ready_d2 (P ints each) + the service's "resident" counter | rowcnt (P x 4 P ints: per panel,
+// per 128-row strip, the tiles of that strip which have received the previous panel)
+size_t panel_service_sync_bytes(int64_t P) { return (size_t)P * sizeof(PanelSync) + (3 * (size_t)P + 16) * sizeof(int) + (size_t)P * TPP * P * sizeof(int); }
 
 // sync: panel_service_sync_bytes(P) bytes of device memory, zeroed by the caller (stream-ordered before this launch)
-int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync) {
+int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync, void* trace) {
   static bool attr_set[MAX_DEVICES] = {};
   const size_t smem = PB_SMEM_DOUBLES * sizeof(double);
   int dev = 0;
@@ -1099,21 +1277,60 @@ int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* w
   PanelSync* sy = reinterpret_cast<PanelSync*>(sync);
   int* ready = reinterpret_cast<int*>(static_cast<char*>(sync) + (size_t)P * sizeof(PanelSync));
   ProfScope ps(s, PK_PANEL_FUSED, 0.0, 0.0);
-  hipLaunchKernelGGL(panel_service_kernel, dim3(3), dim3(512), smem, s, packed, n_pad, winv, info_dev, sy, ready, (int)P);
+  hipLaunchKernelGGL(panel_service_kernel, dim3(SERVICE_WGS), dim3(512), smem, s, packed, n_pad, winv, info_dev, sy, ready, (int)P,
+                     static_cast<unsigned long long*>(trace));
   GPRC_LAUNCH_CHECK();
   return 0;
 }
-int* panel_service_ready(void* sync, int64_t P, int64_t p) { return reinterpret_cast<int*>(static_cast<char*>(sync) + (size_t)P * sizeof(PanelSync)) + p; }
 
-int launch_panel_strips(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync) {
+int launch_service_gate(hipStream_t s, int64_t n_pad, int* info_dev, void* sync) {
+  const int64_t P = n_pad / NB;
+  int* ready = reinterpret_cast<int*>(static_cast<char*>(sync) + (size_t)P * sizeof(PanelSync));
+  hipLaunchKernelGGL(service_gate_kernel, dim3(1), dim3(64), 0, s, ready + 3 * P, SERVICE_WGS, info_dev);
+  GPRC_LAUNCH_CHECK();
+  return 0;
+}
+
+// the ordinary strips of panel p (rows from 2 NB below the panel's top)
+int launch_panel_strips(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync, void* trace) {
   const int64_t ld = panel_ld(n_pad, p), S = ld / 128;
-  if (S <= TPP) return 0;
+  if (S <= 2 * TPP) return 0;
   GPRC_TRY(ensure_gemm_attrs());
   double fl = 0.0;
-  for (int j = 0; j < TPP; ++j) fl += 2.0 * (double)(ld - NB) * NBI * (j * NBI) + (double)(ld - NB) * NBI * NBI;
-  ProfScope ps(s, PK_GEMM_INNER, fl, 8.0 * 2.0 * (double)(ld - NB) * NB);
-  hipLaunchKernelGGL(panel_strips_kernel, dim3((unsigned)(S - TPP)), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)p, winv,
-                     info_dev, reinterpret_cast<PanelSync*>(sync) + p);
+  for (int j = 0; j < TPP; ++j) fl += 2.0 * (double)(ld - 2 * NB) * NBI * (j * NBI) + (double)(ld - 2 * NB) * NBI * NBI;
+  ProfScope ps(s, PK_GEMM_INNER, fl, 8.0 * 2.0 * (double)(ld - 2 * NB) * NB);
+  hipLaunchKernelGGL(panel_strips_kernel, dim3((unsigned)(S - 2 * TPP)), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)p, winv,
+                     info_dev, reinterpret_cast<PanelSync*>(sync) + p, static_cast<unsigned long long*>(trace));
+  GPRC_LAUNCH_CHECK();
+  return 0;
+}
+
+// the caller's-stream kernel of panel p under the service: the trailing update of panel p (everything behind p except the next
+// diagonal block) + the ordinary strips of panel p + 1
+int launch_trailing_service(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync, void* trace) {
+  const int64_t P = n_pad / NB;
+  if (P - p - 1 < 2) return 0;   // one panel left: its diagonal block is all there is, and the service owns it
+  GPRC_TRY(ensure_gemm_attrs());
+  int64_t tiles = -(int64_t)PANEL_DIAG_TILES;
+  double fl = 0.0, by = 0.0;
+  for (int64_t q = p + 1; q < P; ++q) {
+    tiles += (int64_t)TPP * TPP * (P - q) - TPP * (TPP - 1) / 2;
+    const double rows = (double)(n_pad - q * NB);
+    const double elems = rows * NB - 0.5 * NB * (double)(NB - 1) - (q == p + 1 ? 0.5 * NB * (double)(NB + 1) : 0.0);
+    fl += 2.0 * elems * NB;
+    by += 8.0 * (2.0 * elems + rows * NB);
+  }
+  const int64_t ld1 = panel_ld(n_pad, p + 1);
+  const int64_t nstrips = std::max<int64_t>(0, ld1 / 128 - 2 * TPP);
+  for (int j = 0; j < TPP; ++j) fl += nstrips * (2.0 * 128 * NBI * (j * NBI) + 128.0 * NBI * NBI);
+  ProfScope ps(s, PK_TRAILING, fl, by);
+  PanelSync* sy = reinterpret_cast<PanelSync*>(sync);
+  int* ready = reinterpret_cast<int*>(static_cast<char*>(sync) + (size_t)P * sizeof(PanelSync));
+  int* rowcnt = ready + 3 * P + 16;
+  const int64_t n_first = (int64_t)TPP * TPP * (P - p - 1) - TPP * (TPP - 1) / 2 - PANEL_DIAG_TILES;
+  const int64_t base = (n_first + nstrips + 7) & ~(int64_t)7;     // ticketed workgroups, padded to a multiple of the XCD count
+  hipLaunchKernelGGL(trailing_service_kernel, dim3((unsigned)(base + (tiles - n_first))), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)p,
+                     (int)tiles, (int)nstrips, sy, ready, rowcnt, winv, info_dev, static_cast<unsigned long long*>(trace));
   GPRC_LAUNCH_CHECK();
   return 0;
 }
@@ -1133,6 +1350,7 @@ static int ensure_gemm_attrs() {
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_panel_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_strips_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_service_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_left_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_range_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   if (dev >= 0 && dev < MAX_DEVICES) done[dev] = true;
@@ -1227,16 +1445,12 @@ int launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64
 
 // part: 0 all tiles; 1 only the lower tiles of the first target's diagonal block; 2 everything but those
 int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t p, int64_t q_begin, int64_t q_end,
-                           int64_t q_stride, int* ready, int part) {
+                           int64_t q_stride) {
   const int64_t P = n_pad / NB;
   if (q_begin <= p || q_stride <= 0) { set_error("trailing_update: bad panel range"); return GPRC_ERR_ARG; }
   if (q_end > P) q_end = P;
   int64_t tiles = 0, nt = 0;
   for (int64_t q = q_begin; q < q_end; q += q_stride) { tiles += (int64_t)TPP * TPP * (P - q) - TPP * (TPP - 1) / 2; ++nt; }
-  constexpr int64_t DIAG = TPP * (TPP + 1) / 2;
-  int64_t tile_first = 0;
-  if (part == 1) tiles = std::min<int64_t>(tiles, DIAG);
-  else if (part == 2) { tile_first = DIAG; tiles -= DIAG; }
   if (tiles <= 0) return 0;
   GPRC_TRY(ensure_gemm_attrs());
   double fl = 0.0, by = 0.0;  // algorithmic: lower triangle of the 512-wide diagonal block + everything below it
@@ -1246,18 +1460,12 @@ int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t
     fl += 2.0 * elems * NB;
     by += 8.0 * (2.0 * elems + rows * NB);
   }
-  if (part != 0) {   // the two parts of a split update share its algorithmic work in proportion to their tiles
-    int64_t all = 0;
-    for (int64_t q = q_begin; q < q_end; q += q_stride) all += (int64_t)TPP * TPP * (P - q) - TPP * (TPP - 1) / 2;
-    fl *= (double)tiles / (double)all;
-    by *= (double)tiles / (double)all;
-  }
   ProfScope ps(s, PK_TRAILING, fl, by);
 
   static const int pg = std::getenv("GPRC_PERSIST") ? std::atoi(std::getenv("GPRC_PERSIST")) : 0;
   const unsigned grid = (unsigned)((pg > 0 && tiles > pg) ? pg : tiles);
   hipLaunchKernelGGL(trailing_kernel, dim3(grid), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)p,
-                     (int)q_begin, (int)q_stride, (int)nt, (int)tiles, ready, (int)tile_first);
+                     (int)q_begin, (int)q_stride, (int)nt, (int)tiles);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

@@ -300,6 +300,13 @@ GPRC_API int gprc_prof_enable(int on);
  * factored, [2+6j] W_j published, [3+6j] E_{j+1} seen, [4+6j] L(j+1,j) solved, [5+6j] R_{j+1} published, [6+6j] block
  * (j+1,j+1) updated.  side != 0: the context's look-ahead stream's launches.  Measurement only. */
 GPRC_API int gprc_prof_panel_trace(gprc_ctx* ctx, int side, int64_t* ticks_out, int n);
+/* With GPRC_SERVICE_TRACE set, a factor-service sweep (gprc_dev_factor_all and every fit at n <= 24576) leaves 16 stamps per panel
+ * p (100 MHz ticks; 0 = not reached): [14] factor role arrives, [0] its diagonal block is complete: chain starts, [1] chain done;
+ * [2]/[3] look-ahead strips start / done; [4] next-diagonal-block tiles may start, [5] their last k-chunk starts, [6] block
+ * complete; [7]/[8] first ordinary-strip workgroup starts / ends; trailing update: [9] first tile starts, [10] sees the
+ * look-ahead rows, [11] has published, [12] first tile of the block after the next published, [13] last tile done.
+ * panels <= 48.  Measurement only. */
+GPRC_API int gprc_prof_service_trace(gprc_ctx* ctx, int64_t* ticks_out, int panels);
 GPRC_API int gprc_prof_reset(void);
 GPRC_API int gprc_prof_kinds(void);
 GPRC_API int gprc_prof_summary(int kind, int64_t* count_out, double* ms_out, double* flops_out, double* bytes_out);

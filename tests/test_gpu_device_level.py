@@ -76,6 +76,30 @@ def test_sweep_variants_are_bit_identical():
     ctx.close()
 
 
+@pytest.mark.parametrize("n", [600, 1100, 1536, 9100])
+def test_factor_service_is_bit_identical_to_the_launch_per_panel_sweep(n):
+    """gprc_dev_factor_all at these sizes is the factor service (one persistent launch carrying every panel's dependent chain,
+    the rows of the next diagonal block and that block's update; the caller's stream the rest) -- against factor_panel +
+    update_trailing per panel: every word of the factor and of the block inverses equal, twice in a row (the service's
+    flags are per call).  2, 3, 3 (no padding) and 18 panels."""
+    L, ctx, g, K = _filled(n, seed=5)
+    P = g.P
+    a = K.clone(); w, info = _new(g)
+    for p in range(P):
+        nat.check(L.gprc_dev_factor_panel(ctx.handle, a.data_ptr(), g.n_pad, p, w.data_ptr(), info.data_ptr()))
+        if p + 1 < P:
+            nat.check(L.gprc_dev_update_trailing(ctx.handle, a.data_ptr(), g.n_pad, p, p + 1, P, 1))
+    torch.cuda.synchronize()
+    assert int(info[0]) == 0
+    for rep in range(2):
+        b = K.clone(); w2, info2 = _new(g)
+        nat.check(L.gprc_dev_factor_all(ctx.handle, b.data_ptr(), g.n_pad, w2.data_ptr(), info2.data_ptr()))
+        torch.cuda.synchronize()
+        assert int(info2[0]) == 0
+        assert torch.equal(b, a) and torch.equal(w2, w), (n, rep)
+    ctx.close()
+
+
 @pytest.mark.parametrize("n,reps", [(2100, 1), (600, 1), (9100, 2)])
 def test_solve_in_panel_steps_is_bit_identical(n, reps):
     """gprc_dev_trsv (the whole solve) against gprc_dev_trsv_step, the per-panel form the multi-rank sweep runs beside the
