@@ -84,12 +84,14 @@ PROTOTYPES = {
     "gprc_dev_fill_panel": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _i64, C.c_double, _vp, _i64]),
     "gprc_dev_factor_panel": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "gprc_dev_factor_subpanel": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _vp]),
-    "gprc_dev_factor_all": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "gprc_dev_factor_all": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "gprc_solve_inv_size": (_i64, [_i64]),
+    "gprc_dev_solve_prepare": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i64]),
     "gprc_dev_update_trailing": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64]),
     "gprc_dev_update_range": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64]),
     "gprc_trsv_work_size": (_i64, [_i64]),
     "gprc_dev_trsv": (C.c_int, [_vp, _vp, _vp, _i64, _vp, C.c_int, _vp]),
-    "gprc_dev_trsv_step": (C.c_int, [_vp, _vp, _vp, _i64, _vp, C.c_int, _i64]),
+    "gprc_dev_trsv_step": (C.c_int, [_vp, _vp, _vp, _i64, _vp, C.c_int, _i64, _vp]),
     "gprc_dev_fill_cross": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64]),
     "gprc_rowreduce_splits": (_i64, [_i64]),
     "gprc_dev_row_reduce": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),

@@ -399,7 +399,7 @@ int factor_all_lookahead(gprc_ctx* ctx, double* packed, int64_t n_pad, double* w
 // them, the rows of the next diagonal block and that block's update -- runs in ONE persistent ten-workgroup launch on a side
 // stream; the caller's stream carries the ordinary strips and the rest of the trailing update, one launch each per panel, tied to
 // the service by counters.  Same tiles in the same k order: bit-identical.
-int factor_all_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev) {
+int factor_all_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev, double* inv) {
   hipStream_t s = ctx->stream;
   const int64_t P = n_pad / NB;
   if (!ctx->side_stream) {
@@ -419,7 +419,7 @@ int factor_all_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* win
     trace = ctx->svc_trace;
   }
   GPRC_TRY(stream_after(ctx, side, s));                       // the fill, the caller's memset of info and the flag reset precede the service
-  GPRC_TRY(launch_panel_service(side, packed, n_pad, winv, info_dev, sync.p, trace));
+  GPRC_TRY(launch_panel_service(side, packed, n_pad, winv, info_dev, sync.p, trace, inv));
   GPRC_TRY(launch_service_gate(s, n_pad, info_dev, sync.p));  // nothing that waits on the service starts before the service is resident
   GPRC_TRY(launch_panel_strips(s, packed, n_pad, 0, winv, info_dev, sync.p, trace));      // the later panels' strips ride in the update kernels
   for (int64_t p = 0; p + 1 < P; ++p) GPRC_TRY(launch_trailing_service(s, packed, n_pad, p, winv, info_dev, sync.p, trace));
@@ -427,7 +427,9 @@ int factor_all_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* win
   return 0;
 }
 
-int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev) {
+// inv (may be null): n_pad x NB doubles that receive, per panel, the explicit inverse of its diagonal block (transposed) -- what
+// launch_trsv works with; the factor service produces it on the side, the other schedules in one launch after the sweep
+int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev, double* inv) {
   hipStream_t s = ctx->stream;
   const int64_t P = n_pad / NB;
   const char* mode = std::getenv("GPRC_FACTOR");
@@ -439,8 +441,11 @@ int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv,
   static const bool panel_steps = [] { const char* e = std::getenv("GPRC_PANEL"); return e && std::strcmp(e, "steps") == 0; }();
   // GPRC_SERVICE=0 turns the factor service off; it runs up to n_pad = 24576 (beyond that the grouped left-looking schedule wins)
   static const int sv_env = [] { const char* e = std::getenv("GPRC_SERVICE"); return e ? std::atoi(e) : -1; }();
-  if (!mode && !panel_steps && P >= 2 && la_env < 0 && n_pad <= 24576 && sv_env != 0) return factor_all_service(ctx, packed, n_pad, winv, info_dev);
-  if (!mode && !panel_steps && P >= 2 && (la_env == 1 || (la_env < 0 && n_pad <= 24576))) return factor_all_lookahead(ctx, packed, n_pad, winv, info_dev);
+  if (!mode && !panel_steps && P >= 2 && la_env < 0 && n_pad <= 24576 && sv_env != 0) return factor_all_service(ctx, packed, n_pad, winv, info_dev, inv);
+  if (!mode && !panel_steps && P >= 2 && (la_env == 1 || (la_env < 0 && n_pad <= 24576))) {
+    GPRC_TRY(factor_all_lookahead(ctx, packed, n_pad, winv, info_dev));
+    return inv ? launch_inv512(s, packed, n_pad, winv, inv, 0, P) : 0;
+  }
   for (int64_t g0 = 0; g0 < P;) {
     int64_t g1 = g0, tiles = 0;
     while (g1 < P && tiles < want) { tiles += (int64_t)TPP * TPP * (P - g1) - TPP * (TPP - 1) / 2; ++g1; }
@@ -451,13 +456,13 @@ int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv,
     }
     g0 = g1;
   }
-  return 0;
+  return inv ? launch_inv512(s, packed, n_pad, winv, inv, 0, P) : 0;
 }
 
-int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_host) {
+int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_host, double* inv = nullptr) {
   hipStream_t s = ctx->stream;
   GPRC_HIP(hipMemsetAsync(ctx->info_dev, 0, sizeof(int), s));
-  GPRC_TRY(factor_all_async(ctx, packed, n_pad, winv, ctx->info_dev));
+  GPRC_TRY(factor_all_async(ctx, packed, n_pad, winv, ctx->info_dev, inv));
   GPRC_HIP(hipMemcpyAsync(info_host, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
   GPRC_HIP(hipStreamSynchronize(s));
   if (*info_host < 0) { set_error("fused panel kernel: a device-side dependency wait timed out (info = " + std::to_string(*info_host) + "); the factor is not valid"); return GPRC_ERR_HIP; }
@@ -556,11 +561,13 @@ int gpr_attempt(gprc_model* m, double noise, int* info_out) {
   for (int64_t p = 0; p < P; ++p)
     GPRC_TRY(launch_fill(s, m->ks, m->X, n, m->X, n, m->d, m->packed + panel_offset(n_pad, p), panel_ld(n_pad, p), p * NB,
                          n_pad - p * NB, p * NB, NB, PAD_IDENTITY, noise));
-  GPRC_TRY(factor_all(ctx, m->packed, n_pad, m->winv, info_out));
+  DevMem inv;   // explicit inverses of the diagonal blocks: needed by the two vector solves only
+  GPRC_TRY(inv.alloc(gprc_solve_inv_size(n_pad)));
+  GPRC_TRY(factor_all(ctx, m->packed, n_pad, m->winv, info_out, inv.p));
   if (*info_out != 0) return 0;
   GPRC_HIP(hipMemcpyAsync(m->alpha, m->y, sizeof(double) * n_pad, hipMemcpyDeviceToDevice, s));
-  GPRC_TRY(launch_trsv(s, m->packed, m->winv, n_pad, m->alpha, 0, m->work));
-  GPRC_TRY(launch_trsv(s, m->packed, m->winv, n_pad, m->alpha, 1, m->work));
+  GPRC_TRY(launch_trsv(s, m->packed, inv.p, n_pad, m->alpha, 0, m->work));
+  GPRC_TRY(launch_trsv(s, m->packed, inv.p, n_pad, m->alpha, 1, m->work));
   GPRC_TRY(launch_logp(s, m->packed, n_pad, n, m->y, m->alpha, ctx->scal_dev));
   GPRC_HIP(hipMemcpyAsync(&m->logp, ctx->scal_dev, sizeof(double), hipMemcpyDeviceToHost, s));
   GPRC_HIP(hipStreamSynchronize(s));
@@ -1079,6 +1086,8 @@ int gprc_gpc_fit(gprc_ctx* ctx, int kernel, const double* params, int n_params, 
     const int64_t nc = (n_pad - c0 < 32768) ? n_pad - c0 : 32768;
     GPC_TRY(launch_fill(s, ks, m->X, n, m->X, n, d, Kf.p + c0 * n_pad, n_pad, 0, n_pad, c0, nc, PAD_ZERO, 0.0));
   }
+  DevMem inv;   // explicit inverses of B's diagonal blocks, for the two vector solves of an iteration
+  GPC_TRY(inv.alloc(gprc_solve_inv_size(n_pad)));
   int it = 0;
   double objective = 0.0, last_objective = 0.0, least_objective = 0.0;
   int status = 0;
@@ -1087,12 +1096,12 @@ int gprc_gpc_fit(gprc_ctx* ctx, int kernel, const double* params, int n_params, 
     GPC_TRY(launch_gpc_pre(s, f, m->y, n, m->sw, b));                       // :78-81
     GPC_TRY(launch_gpc_build_B(s, Kf.p, n_pad, m->sw, m->packed));           // :80
     int info = 0;
-    GPC_TRY(factor_all(ctx, m->packed, n_pad, m->winv, &info));
+    GPC_TRY(factor_all(ctx, m->packed, n_pad, m->winv, &info, inv.p));
     if (info != 0) { free_model(m); set_error("GPC: I + sqrt(W) K sqrt(W) not positive definite"); return info; }
     GPC_TRY(launch_row_reduce(s, Kf.p, n_pad, n_pad, n_pad, b, t, red.p));  // K %*% b
     GPC_TRY(launch_gpc_scale(s, m->sw, t, t, n_pad));                        // sqrt(W) * .
-    GPC_TRY(launch_trsv(s, m->packed, m->winv, n_pad, t, 0, m->work));       // :82
-    GPC_TRY(launch_trsv(s, m->packed, m->winv, n_pad, t, 1, m->work));       // :83
+    GPC_TRY(launch_trsv(s, m->packed, inv.p, n_pad, t, 0, m->work));         // :82
+    GPC_TRY(launch_trsv(s, m->packed, inv.p, n_pad, t, 1, m->work));         // :83
     GPC_TRY(launch_gpc_a(s, b, m->sw, t, a, n_pad));                         // :84
     GPC_TRY(launch_row_reduce(s, Kf.p, n_pad, n_pad, n_pad, a, f, red.p));  // f <- K %*% a  :85
     GPC_TRY(launch_gpc_objective(s, a, f, m->y, n, ctx->scal_dev));          // :86
@@ -1205,7 +1214,8 @@ int64_t gprc_panel_offset(int64_t n_pad, int64_t p) { return panel_offset(n_pad,
 int64_t gprc_panel_elems(int64_t n_pad, int64_t p) { return panel_ld(n_pad, p) * NB; }
 int64_t gprc_packed_size(int64_t n_pad) { return panel_offset(n_pad, n_pad / NB); }
 int64_t gprc_winv_size(int64_t n_pad) { return n_pad * NBI; }
-int64_t gprc_trsv_work_size(int64_t n_pad) { return (n_pad / 1024 + 2) * 128; }
+int64_t gprc_trsv_work_size(int64_t n_pad) { return n_pad + n_pad / NB + 8; }   // x_p staging + one gate (8 bytes) per panel
+int64_t gprc_solve_inv_size(int64_t n_pad) { return n_pad * NB; }
 int64_t gprc_rowreduce_splits(int64_t cols) { return rowreduce_splits(cols); }
 
 int gprc_dev_fill_panel(gprc_ctx* ctx, int kernel, const double* params_host, int n_params, const double* X,
@@ -1232,10 +1242,15 @@ int gprc_dev_factor_subpanel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64
   }
   return factor_subpanel(ctx, packed, n_pad, p, j, part, winv, info_dev);
 }
-int gprc_dev_factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev) {
+int gprc_dev_factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev, double* inv) {
   GPRC_TRY(use_device(ctx));
   if (!packed || !winv || !info_dev || n_pad <= 0 || n_pad % NB) { set_error("dev_factor_all: bad arguments"); return GPRC_ERR_ARG; }
-  return factor_all_async(ctx, packed, n_pad, winv, info_dev);
+  return factor_all_async(ctx, packed, n_pad, winv, info_dev, inv);
+}
+int gprc_dev_solve_prepare(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* inv, int64_t p_begin, int64_t p_end) {
+  GPRC_TRY(use_device(ctx));
+  if (!packed || !winv || !inv || n_pad <= 0 || n_pad % NB || p_begin < 0 || p_end > n_pad / NB) { set_error("dev_solve_prepare: bad arguments"); return GPRC_ERR_ARG; }
+  return launch_inv512(ctx->stream, packed, n_pad, winv, inv, p_begin, p_end);
 }
 int gprc_dev_update_range(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p_begin, int64_t p_end, int64_t q_begin, int64_t q_end,
                           int64_t q_stride) {
@@ -1252,16 +1267,17 @@ int gprc_dev_update_trailing(gprc_ctx* ctx, double* packed, int64_t n_pad, int64
   return launch_trailing_update(ctx->stream, packed, n_pad, p, q_begin, q_end, q_stride);
 }
 
-int gprc_dev_trsv(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose,
+int gprc_dev_trsv(gprc_ctx* ctx, const double* packed, const double* inv, int64_t n_pad, double* b, int transpose,
                   double* work) {
   GPRC_TRY(use_device(ctx));
-  return launch_trsv(ctx->stream, packed, winv, n_pad, b, transpose, work);
+  if (!packed || !inv || !b || !work || n_pad <= 0 || n_pad % NB) { set_error("dev_trsv: bad arguments"); return GPRC_ERR_ARG; }
+  return launch_trsv(ctx->stream, packed, inv, n_pad, b, transpose, work);
 }
 
-int gprc_dev_trsv_step(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose, int64_t p) {
+int gprc_dev_trsv_step(gprc_ctx* ctx, const double* packed, const double* inv, int64_t n_pad, double* b, int transpose, int64_t p, double* work) {
   GPRC_TRY(use_device(ctx));
-  if (!packed || !winv || !b || n_pad <= 0 || n_pad % NB) { set_error("dev_trsv_step: bad arguments"); return GPRC_ERR_ARG; }
-  return launch_trsv_step(ctx->stream, packed, winv, n_pad, b, transpose, (int)p);
+  if (!packed || !inv || !b || !work || n_pad <= 0 || n_pad % NB) { set_error("dev_trsv_step: bad arguments"); return GPRC_ERR_ARG; }
+  return launch_trsv_step(ctx->stream, packed, inv, n_pad, b, transpose, (int)p, work);
 }
 
 int gprc_dev_fill_cross(gprc_ctx* ctx, int kernel, const double* params_host, int n_params, const double* X_star,

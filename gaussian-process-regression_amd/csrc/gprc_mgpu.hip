@@ -99,7 +99,7 @@ struct gprc_mgpu_model {
   std::vector<double> params;
   int64_t n = 0, d = 0, n_pad = 0;
   double noise = 0.0, logp = 0.0;
-  struct PerRank { double *X = nullptr, *y = nullptr, *packed = nullptr, *winv = nullptr, *alpha = nullptr, *work = nullptr, *scal = nullptr; int* info = nullptr; gprc_model* model = nullptr; };
+  struct PerRank { double *X = nullptr, *y = nullptr, *packed = nullptr, *winv = nullptr, *inv = nullptr, *alpha = nullptr, *work = nullptr, *scal = nullptr; int* info = nullptr; gprc_model* model = nullptr; };
   std::vector<PerRank> pr;
   std::vector<double> alpha_host;
 };
@@ -139,7 +139,7 @@ void free_model_buffers(gprc_mgpu_model* m) {
     auto& b = m->pr[r];
     (void)hipSetDevice(m->mg->ranks[r].device);
     if (b.model) gprc_model_free(b.model);
-    for (void* p : {(void*)b.X, (void*)b.y, (void*)b.packed, (void*)b.winv, (void*)b.alpha, (void*)b.work, (void*)b.scal, (void*)b.info})
+    for (void* p : {(void*)b.X, (void*)b.y, (void*)b.packed, (void*)b.winv, (void*)b.inv, (void*)b.alpha, (void*)b.work, (void*)b.scal, (void*)b.info})
       if (p) (void)hipFree(p);
   }
   delete m;
@@ -200,7 +200,7 @@ int mgpu_attempt(gprc_mgpu* mg, gprc_mgpu_model* m, double noise, int* info_out)
   }
   if (G == 1 && !mg->use_rccl) {
     Rank& k = mg->ranks[0];
-    GPRC_TRY(gprc_dev_factor_all(k.ctx_main, m->pr[0].packed, n_pad, m->pr[0].winv, m->pr[0].info));
+    GPRC_TRY(gprc_dev_factor_all(k.ctx_main, m->pr[0].packed, n_pad, m->pr[0].winv, m->pr[0].info, m->pr[0].inv));
   } else {
     auto factor_and_share = [&](int64_t p) -> int {
       const int src = (int)(p % G);
@@ -267,8 +267,10 @@ int mgpu_attempt(gprc_mgpu* mg, gprc_mgpu_model* m, double noise, int* info_out)
     Rank& k = mg->ranks[r];
     MG_HIP(hipSetDevice(k.device));
     MG_HIP(hipMemcpyAsync(m->pr[r].alpha, m->pr[r].y, sizeof(double) * n_pad, hipMemcpyDeviceToDevice, k.main));
-    GPRC_TRY(gprc_dev_trsv(k.ctx_main, m->pr[r].packed, m->pr[r].winv, n_pad, m->pr[r].alpha, 0, m->pr[r].work));
-    GPRC_TRY(gprc_dev_trsv(k.ctx_main, m->pr[r].packed, m->pr[r].winv, n_pad, m->pr[r].alpha, 1, m->pr[r].work));
+    // the explicit diagonal-block inverses the vector solves work with: every rank computes its own copy (never exchanged)
+    if (!(G == 1 && !mg->use_rccl)) GPRC_TRY(gprc_dev_solve_prepare(k.ctx_main, m->pr[r].packed, m->pr[r].winv, n_pad, m->pr[r].inv, 0, P));
+    GPRC_TRY(gprc_dev_trsv(k.ctx_main, m->pr[r].packed, m->pr[r].inv, n_pad, m->pr[r].alpha, 0, m->pr[r].work));
+    GPRC_TRY(gprc_dev_trsv(k.ctx_main, m->pr[r].packed, m->pr[r].inv, n_pad, m->pr[r].alpha, 1, m->pr[r].work));
     GPRC_TRY(gprc_dev_logp(k.ctx_main, m->pr[r].packed, n_pad, n, m->pr[r].y, m->pr[r].alpha, m->pr[r].scal));
   }
   m->alpha_host.resize((size_t)n);
@@ -304,6 +306,7 @@ int mgpu_prepare(gprc_mgpu* mg, int kernel, const double* params, int n_params, 
     A((void**)&b.y, sizeof(double) * n_pad);
     A((void**)&b.packed, sizeof(double) * gprc_packed_size(n_pad));
     A((void**)&b.winv, sizeof(double) * gprc_winv_size(n_pad));
+    A((void**)&b.inv, sizeof(double) * gprc_solve_inv_size(n_pad));
     A((void**)&b.alpha, sizeof(double) * n_pad);
     A((void**)&b.work, sizeof(double) * gprc_trsv_work_size(n_pad));
     A((void**)&b.scal, 64);

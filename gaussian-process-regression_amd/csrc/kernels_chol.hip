@@ -1003,12 +1003,56 @@ __global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_
 }
 
 // ------------------------------------------------------------------------------------------------
+// The explicit inverse of a panel's NB x NB diagonal block, for the triangular solves with vectors (kernels_vec.hip).
+//
+// x_p = L_pp^-1 b_p through the four 128-block inverses is a chain of eight dependent small products -- 35 us in one workgroup,
+// half of every panel step of a solve.  With inv(L_pp) explicit it is ONE 512 x 512 product, spread over 16 workgroups.
+// Stored TRANSPOSED: T = inv(L_pp)^T, column-major with ld = NB, so that row r of the inverse is the NB contiguous doubles at
+// T + r NB.  Block row j of T (128-blocks) from the W_i the factorisation leaves in winv:
+//   T(j, j) = W_j^T
+//   T(j, i) = -( sum_{k = j}^{i-1} T(j, k) L(i, k)^T ) W_i^T        i > j      [inv(i, j) = -W_i sum_k L(i, k) inv(k, j), transposed]
+// i.e. per block one accumulating gemm_tile_128 call from a zeroed tile (K = 128 (i - j): the blocks T(j, j..i-1) and L(i, j..i-1)
+// are contiguous strips) and one X := X W^T call.  Blocks below the diagonal of T are never written and never read.
+// One 4-wave team per block row.  sy != null (factor service): block (j, i) waits for W_i of the panel being factored.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void inv512_row_role(double* smem, const double* pan, int64_t ld, const double* wp, double* T, int j, int tid,
+                                                PanelSync* sy, int* info) {
+  if (sy) panel_flag_wait(&sy->W[j], sy, info);
+  {
+    const double* W = wp + (int64_t)j * NBI * NBI;
+    double* Tjj = T + (int64_t)j * 128 + (int64_t)j * 128 * NB;
+    for (int e = tid; e < 128 * 128; e += 256) Tjj[(e & 127) + (int64_t)(e >> 7) * NB] = W[(e >> 7) + (e & 127) * 128];   // T[c, r] = W[r, c]
+  }
+  for (int i = j + 1; i < TPP; ++i) {
+    double* C = T + (int64_t)j * 128 + (int64_t)i * 128 * NB;
+    for (int e = tid; e < 128 * 128; e += 256) C[(e & 127) + (int64_t)(e >> 7) * NB] = 0.0;
+    if (sy) panel_flag_wait(&sy->W[i], sy, info);        // (its vmcnt(0) + barrier also settle the stores above for the team's loads)
+    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+    gemm_tile_128<false>(C, NB, T + (int64_t)j * 128 + (int64_t)j * 128 * NB, NB, pan + (int64_t)i * 128 + (int64_t)j * 128 * ld, ld, 128 * (i - j), smem,
+                         0, 0, 0, nullptr, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gemm_tile_128<true>(C, NB, C, NB, wp + (int64_t)i * NBI * NBI, 128, 128, smem, 0, 0, 0, nullptr, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
+// panels [p0, p0 + gridDim.x / TPP): one workgroup per block row
+__global__ __launch_bounds__(256, 2) void inv512_kernel(const double* packed, int64_t n_pad, const double* winv, double* inv, int p0) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int p = p0 + (int)blockIdx.x / TPP, j = (int)blockIdx.x % TPP;
+  inv512_row_role(smem, packed + panel_offset(n_pad, p), panel_ld(n_pad, p), winv + (int64_t)p * TPP * NBI * NBI, inv + (int64_t)p * NB * NB, j,
+                  (int)threadIdx.x, nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
 // The factor SERVICE: the whole dependent chain of a factorisation in one persistent launch (one-GPU right-looking sweep,
 // n <= 24576).
 //
 // With one fused launch per panel the chain of panel p + 1 (330 us) starts only when the trailing update of panel p has drained,
-// and run beside that update on a second stream its workgroups queue for whole CUs behind the update's GEMM tiles.  Here 17
-// workgroups are launched ONCE per factorisation on a side stream and stay resident (17 of 256 CUs); they walk through the panels:
+// and run beside that update on a second stream its workgroups queue for whole CUs behind the update's GEMM tiles.  Here 21
+// workgroups are launched ONCE per factorisation on a side stream and stay resident (21 of 256 CUs); they walk through the panels:
 //   role 0        the factor role of the fused kernel (diagonal blocks + the two tiles each next one waits for)
 //   roles 1, 2    the diagonal strips 2 and 3 (they also count their finished blocks (s, j <= s-2) into E[0] / E[1])
 //   roles 3..6    LOOK-AHEAD strips 4..7: the rows of panel p that are the rows of the NEXT diagonal block; after every finished
@@ -1017,6 +1061,8 @@ __global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_
 //                 (LA >= 4 (j + 1)), D(a, b) -= L(4+a, j) L(4+b, j)^T -- the K = 512 update of that tile in its four k-chunks, in
 //                 order, continuing one accumulator chain through memory -- and after chunk 3 they count themselves into
 //                 ready[p + 1], on which roles 0..2 start panel p + 1.
+//   roles 17..20  (when the caller wants it) the explicit inverse of the panel's diagonal block for the vector solves, one block
+//                 row each, paced by the W flags (inv512_row_role) -- off the chain
 // (One 4-wave team per CU: two teams sharing a CU ran a K = 128 tile in ~39 us instead of ~20, and those tiles are the path
 // between two panels' chains.)  So the distance between two chains is one 128-column solve + one K = 128 tile, with no kernel
 // launch, no drained GPU and no contended CU on it.  The caller's stream carries only throughput work, one launch per panel
@@ -1034,7 +1080,8 @@ constexpr int PANEL_DIAG_TILES = TPP * (TPP + 1) / 2;
 constexpr int PANEL_LA_TILES = TPP * TPP;             // tiles of a panel's rows [NB, 2 NB)
 constexpr int SERVICE_LA0 = 3;                                   // first look-ahead strip role (one 4-wave team per workgroup)
 constexpr int SERVICE_D0 = SERVICE_LA0 + TPP;                    // first next-diagonal-block role (one tile per workgroup)
-constexpr int SERVICE_WGS = SERVICE_D0 + PANEL_DIAG_TILES;
+constexpr int SERVICE_INV0 = SERVICE_D0 + PANEL_DIAG_TILES;     // first explicit-inverse role (one block row of inv(L_pp)^T each)
+constexpr int SERVICE_WGS = SERVICE_INV0 + TPP;
 
 // One team's share of the next diagonal block: lower tile `idx` (0..9: (0,0) (1,0) (1,1) (2,0) ...) of the block, in four k-chunks.
 __device__ __forceinline__ void panel_next_diag_role(double* smem, const double* pan, int64_t ld, double* Dn, int64_t ldn, int* info,
@@ -1059,12 +1106,13 @@ __device__ __forceinline__ void panel_next_diag_role(double* smem, const double*
 #define SERVICE_STAMP(p, k) do { if (trace && (threadIdx.x & 255) == 0) trace[16 * (p) + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 __global__ __launch_bounds__(512) void panel_service_kernel(double* packed, int64_t n_pad, double* winv, int* info, PanelSync* sy_base,
-                                                            int* ready, int P, unsigned long long* trace) {
+                                                            int* ready, int P, unsigned long long* trace, double* inv) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int role = blockIdx.x;
   const int t = threadIdx.x, team = t >> 8, tid = t & 255;
   if (t == 0) __hip_atomic_fetch_add(&ready[3 * P], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident: see service_gate_kernel
   if (role >= 1 && team == 1) return;                // every role but the factor role is one 4-wave team
+  if (role >= SERVICE_INV0 && !inv) return;
   for (int p = 0; p < P; ++p) {
     PanelSync* sy = sy_base + p;
     const int64_t ld = panel_ld(n_pad, p);
@@ -1077,6 +1125,8 @@ __global__ __launch_bounds__(512) void panel_service_kernel(double* packed, int6
       if (role == 0) panel_factor_role(sm, pan, ld, wp, info, p, sy, nullptr);
       else panel_strip_role(sm, pan, ld, wp, info, sy, role + 1, tid, &sy->E[role - 1], 1);
       if (role == 0) SERVICE_STAMP(p, 1);
+    } else if (role >= SERVICE_INV0) {
+      inv512_row_role(sm, pan, ld, wp, inv + (int64_t)p * NB * NB, role - SERVICE_INV0, tid, sy, info);
     } else if (p + 1 < P) {
       if (role < SERVICE_D0) {
         if (p > 0) panel_ready_wait(&ready[P + p], PANEL_LA_TILES, sy, info);
@@ -1089,7 +1139,7 @@ __global__ __launch_bounds__(512) void panel_service_kernel(double* packed, int6
         panel_next_diag_role(sm, pan, ld, packed + panel_offset(n_pad, p + 1), panel_ld(n_pad, p + 1), info, sy, role - SERVICE_D0, tid,
                              (role == SERVICE_D0 && trace) ? trace + 16 * p + 5 : nullptr);
         panel_count_publish(&ready[p + 1], 1);
-        if (role == SERVICE_WGS - 1) SERVICE_STAMP(p, 6);
+        if (role == SERVICE_INV0 - 1) SERVICE_STAMP(p, 6);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1264,7 +1314,16 @@ static int ensure_gemm_attrs();
 size_t panel_service_sync_bytes(int64_t P) { return (size_t)P * sizeof(PanelSync) + (3 * (size_t)P + 16) * sizeof(int) + (size_t)P * TPP * P * sizeof(int); }
 
 // sync: panel_service_sync_bytes(P) bytes of device memory, zeroed by the caller (stream-ordered before this launch)
-int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync, void* trace) {
+int launch_inv512(hipStream_t s, const double* packed, int64_t n_pad, const double* winv, double* inv, int64_t p_begin, int64_t p_end) {
+  if (p_end <= p_begin) return 0;
+  GPRC_TRY(ensure_gemm_attrs());
+  hipLaunchKernelGGL(inv512_kernel, dim3((unsigned)((p_end - p_begin) * TPP)), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, winv, inv,
+                     (int)p_begin);
+  GPRC_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync, void* trace, double* inv) {
   static bool attr_set[MAX_DEVICES] = {};
   const size_t smem = PB_SMEM_DOUBLES * sizeof(double);
   int dev = 0;
@@ -1278,7 +1337,7 @@ int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* w
   int* ready = reinterpret_cast<int*>(static_cast<char*>(sync) + (size_t)P * sizeof(PanelSync));
   ProfScope ps(s, PK_PANEL_FUSED, 0.0, 0.0);
   hipLaunchKernelGGL(panel_service_kernel, dim3(SERVICE_WGS), dim3(512), smem, s, packed, n_pad, winv, info_dev, sy, ready, (int)P,
-                     static_cast<unsigned long long*>(trace));
+                     static_cast<unsigned long long*>(trace), inv);
   GPRC_LAUNCH_CHECK();
   return 0;
 }
@@ -1351,6 +1410,7 @@ static int ensure_gemm_attrs() {
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_strips_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_service_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(inv512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_left_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_range_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   if (dev >= 0 && dev < MAX_DEVICES) done[dev] = true;

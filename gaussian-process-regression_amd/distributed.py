@@ -202,6 +202,32 @@ class HipOps:
         self.d, self.n, self.noise = int(d), int(n), float(noise)
         self.geom = Geometry(n)
         self.L = nat.lib()
+        # the explicit inverses of the panels' diagonal blocks the vector solves work with (gprc_dev_solve_prepare): computed
+        # where the solve runs -- every rank for every panel, on the auxiliary stream beside the sweep -- never exchanged
+        self.inv = None
+        self._prepared = set()
+
+    def begin_fit(self):
+        self._prepared = set()
+
+    def _solve_inv(self):
+        if self.inv is None:
+            self.inv = self.zeros(int(self.L.gprc_solve_inv_size(self.geom.n_pad)))
+        return self.inv
+
+    def _prepare(self, ctx, packed, winv, panels):
+        """gprc_dev_solve_prepare for the listed panels that have not been prepared since begin_fit (runs of consecutive panels
+        in one launch)."""
+        todo = sorted(p for p in panels if p not in self._prepared)
+        inv = self._solve_inv()
+        i = 0
+        while i < len(todo):
+            j = i
+            while j + 1 < len(todo) and todo[j + 1] == todo[j] + 1:
+                j += 1
+            nat.check(self.L.gprc_dev_solve_prepare(ctx, packed.data_ptr(), winv.data_ptr(), self.geom.n_pad, inv.data_ptr(), todo[i], todo[j] + 1))
+            i = j + 1
+        self._prepared.update(todo)
 
     # ---- memory ----
     def zeros(self, count, dtype=None):
@@ -274,7 +300,9 @@ class HipOps:
     def factor_all(self, packed, winv, info):
         """Every panel on this one GPU (no exchange): the native grouped left-looking sweep, bit-identical to the
         factor_panel / update_trailing loop."""
-        nat.check(self.L.gprc_dev_factor_all(self._ctx(False), packed.data_ptr(), self.geom.n_pad, winv.data_ptr(), info.data_ptr()))
+        nat.check(self.L.gprc_dev_factor_all(self._ctx(False), packed.data_ptr(), self.geom.n_pad, winv.data_ptr(), info.data_ptr(),
+                                             self._solve_inv().data_ptr()))
+        self._prepared = set(range(self.geom.P))
 
     def update_trailing(self, packed, p, q0, q1, stride, side):
         if q0 < q1:
@@ -287,13 +315,16 @@ class HipOps:
             nat.check(self.L.gprc_dev_update_range(self._ctx(side), packed.data_ptr(), self.geom.n_pad, p0, p1, q0, q1, stride))
 
     def trsv(self, packed, winv, b, transpose, work):
-        nat.check(self.L.gprc_dev_trsv(self._ctx(False), packed.data_ptr(), winv.data_ptr(), self.geom.n_pad, b.data_ptr(), int(transpose),
+        self._prepare(self._ctx(False), packed, winv, range(self.geom.P))
+        nat.check(self.L.gprc_dev_trsv(self._ctx(False), packed.data_ptr(), self.inv.data_ptr(), self.geom.n_pad, b.data_ptr(), int(transpose),
                                        work.data_ptr()))
 
-    def trsv_step_aux(self, packed, winv, b, p):
-        """Forward-solve step of panel p on the auxiliary stream."""
+    def trsv_step_aux(self, packed, winv, b, p, work):
+        """Forward-solve step of panel p on the auxiliary stream (the panel's explicit diagonal inverse first)."""
         with self.torch.cuda.stream(self.aux_stream):
-            nat.check(self.L.gprc_dev_trsv_step(self.ctx_aux.handle, packed.data_ptr(), winv.data_ptr(), self.geom.n_pad, b.data_ptr(), 0, p))
+            self._prepare(self.ctx_aux.handle, packed, winv, [p])
+            nat.check(self.L.gprc_dev_trsv_step(self.ctx_aux.handle, packed.data_ptr(), self.inv.data_ptr(), self.geom.n_pad, b.data_ptr(), 0, p,
+                                                work.data_ptr()))
 
     def logp(self, packed, y, alpha, out):
         nat.check(self.L.gprc_dev_logp(self._ctx(False), packed.data_ptr(), self.geom.n_pad, self.n, y.data_ptr(), alpha.data_ptr(),
@@ -365,6 +396,8 @@ class DistributedGPR:
         """X: d x n device buffer (point-major); y_pad: n_pad doubles, zero padded.  Returns LAPACK info."""
         ops, comm, g = self.ops, self.comm, self.geom
         rank, G, P = comm.rank, comm.world, g.P
+        if hasattr(ops, "begin_fit"):
+            ops.begin_fit()
         with ops.on(False):
             self.info.zero_() if hasattr(self.info, "zero_") else self.info.fill(0)
             for p in range(rank, P, G):                       # F1: own panels only, no communication
@@ -386,7 +419,7 @@ class DistributedGPR:
         for p in range(P):                                    # F2: right-looking, one panel per step
             if self._fwd_in_sweep:
                 ops.aux_after_panel()                         # panel p and its inverses are complete on side / comm
-                ops.trsv_step_aux(self.packed, self.winv, self.alpha, p)
+                ops.trsv_step_aux(self.packed, self.winv, self.alpha, p, self.work)
             ops.join_side()                                   # panel p factored (owner) / received (others)
             if p + 1 < P:
                 nxt = (p + 1) % G

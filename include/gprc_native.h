@@ -187,9 +187,11 @@ GPRC_API int gprc_dev_factor_panel(gprc_ctx* ctx, double* packed, int64_t n_pad,
 GPRC_API int gprc_dev_factor_subpanel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, int j, int part, double* winv,
                              int* info_dev);
 /* All panels of an already filled packed matrix on ONE GPU, asynchronously on the context's stream (the one-rank form of
- * the factor_panel / update_trailing sweep): grouped left-looking schedule, results bit-identical to that sweep.
- * info_dev: one device int, zeroed by the caller, receives LAPACK's info (first non-PD leading minor) if any. */
-GPRC_API int gprc_dev_factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev);
+ * the factor_panel / update_trailing sweep; the factor service up to n_pad = 24576, the grouped left-looking schedule beyond):
+ * results bit-identical to that sweep.
+ * info_dev: one device int, zeroed by the caller, receives LAPACK's info (first non-PD leading minor) if any.
+ * inv: NULL, or gprc_solve_inv_size(n_pad) doubles that receive what gprc_dev_solve_prepare would compute for all panels. */
+GPRC_API int gprc_dev_factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev, double* inv);
 /* trailing update of panels q = q_begin, q_begin + q_stride, ... < q_end with factored panel p */
 GPRC_API int gprc_dev_update_trailing(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, int64_t q_begin,
                              int64_t q_end, int64_t q_stride);
@@ -198,14 +200,22 @@ GPRC_API int gprc_dev_update_trailing(gprc_ctx* ctx, double* packed, int64_t n_p
  * ... < q_end must all lie behind the range (q_begin >= p_end). */
 GPRC_API int gprc_dev_update_range(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p_begin, int64_t p_end, int64_t q_begin,
                           int64_t q_end, int64_t q_stride);
-/* b := L^-1 b (transpose == 0) or L^-T b (transpose != 0); work: gprc_trsv_work_size(n_pad) doubles */
+/* The solves with VECTORS (alpha <- solve(t(L), solve(L, y)), R/GPRclass.R:152, R/GPCclass.R:82-83) work with the explicit inverse
+ * of every panel's NB x NB diagonal block: inv, gprc_solve_inv_size(n_pad) doubles, panel p's inverse (transposed, ld = NB) at
+ * inv + p NB NB.  gprc_dev_solve_prepare computes it for the factored panels [p_begin, p_end) from packed and winv (one launch);
+ * gprc_dev_factor_all does it itself when given inv. */
+GPRC_API int64_t gprc_solve_inv_size(int64_t n_pad);
+GPRC_API int gprc_dev_solve_prepare(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* inv, int64_t p_begin,
+                           int64_t p_end);
+/* b := L^-1 b (transpose == 0) or L^-T b (transpose != 0), one launch per panel; work: gprc_trsv_work_size(n_pad) doubles */
 GPRC_API int64_t gprc_trsv_work_size(int64_t n_pad);
-GPRC_API int gprc_dev_trsv(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose,
+GPRC_API int gprc_dev_trsv(gprc_ctx* ctx, const double* packed, const double* inv, int64_t n_pad, double* b, int transpose,
                   double* work);
 /* one panel step of that solve (forward: p = 0, 1, ...; transposed: p = P-1, ..., 0): the forward solve needs only
- * panels <= p, so a sweep that produces the panels in order can run it beside the factorisation */
-GPRC_API int gprc_dev_trsv_step(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* b, int transpose,
-                       int64_t p);
+ * panels <= p, so a sweep that produces the panels in order can run it beside the factorisation.  The same launch as inside
+ * gprc_dev_trsv: identical bits.  work as above (one buffer for the whole sequence of steps). */
+GPRC_API int gprc_dev_trsv_step(gprc_ctx* ctx, const double* packed, const double* inv, int64_t n_pad, double* b, int transpose,
+                       int64_t p, double* work);
 /* vt (m_pad x n_pad, leading dimension ld >= m_pad, ld even, m_pad % 128 == 0) = K(X_star, X), zero in the
  * padding.  Keep ld off powers of two (e.g. m_pad + 128): a 2^k-byte column stride aliases HBM channels. */
 GPRC_API int gprc_dev_fill_cross(gprc_ctx* ctx, int kernel, const double* params_host, int n_params, const double* X_star,

@@ -145,7 +145,7 @@ class OracleOps:
     def join_aux(self):
         self.log.append(("join_aux",))
 
-    def trsv_step_aux(self, packed, winv, b, p):
+    def trsv_step_aux(self, packed, winv, b, p, work=None):
         """Forward-substitution step of panel p: z_p = L_pp^-1 z_p, then z_below -= L[below, p] z_p."""
         g = self.geom
         pan = self._panel(packed, p)

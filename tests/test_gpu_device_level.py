@@ -32,6 +32,13 @@ def _new(g):
     return (torch.zeros(g.winv_size, dtype=torch.float64, device="cuda"), torch.zeros(4, dtype=torch.int32, device="cuda"))
 
 
+def _new_inv(g):
+    return torch.full((int(nat.lib().gprc_solve_inv_size(g.n_pad)),), float("nan"), dtype=torch.float64, device="cuda")
+
+
+NULL = None
+
+
 def test_sweep_variants_are_bit_identical():
     n = 2900                                             # 6 panels
     L, ctx, g, K = _filled(n)
@@ -63,7 +70,7 @@ def test_sweep_variants_are_bit_identical():
 
     def whole():
         a = K.clone(); w, info = _new(g)
-        nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr()))
+        nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr(), NULL))
         torch.cuda.synchronize()
         return a, w, int(info[0])
 
@@ -93,78 +100,65 @@ def test_factor_service_is_bit_identical_to_the_launch_per_panel_sweep(n):
     assert int(info[0]) == 0
     for rep in range(2):
         b = K.clone(); w2, info2 = _new(g)
-        nat.check(L.gprc_dev_factor_all(ctx.handle, b.data_ptr(), g.n_pad, w2.data_ptr(), info2.data_ptr()))
+        inv2 = _new_inv(g) if rep else None      # with and without the explicit diagonal inverses riding along
+        nat.check(L.gprc_dev_factor_all(ctx.handle, b.data_ptr(), g.n_pad, w2.data_ptr(), info2.data_ptr(), inv2.data_ptr() if rep else NULL))
         torch.cuda.synchronize()
         assert int(info2[0]) == 0
         assert torch.equal(b, a) and torch.equal(w2, w), (n, rep)
+    # the inverses the service leaves are the ones gprc_dev_solve_prepare computes (same block arithmetic; entries below T's
+    # block diagonal are never written: compare through a mask), and they invert the diagonal blocks
+    inv1 = _new_inv(g)
+    nat.check(L.gprc_dev_solve_prepare(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, inv1.data_ptr(), 0, P))
+    torch.cuda.synchronize()
+    T1 = inv1.view(P, 512, 512); T2 = inv2.view(P, 512, 512)               # [p, r, c] = T[c + r NB] = inv(L_pp)[r, c]
+    blk = torch.arange(512, device="cuda") // 128
+    written = (blk[None, :] <= blk[:, None])                                # inverse entry (r, c): block row >= block column
+    assert torch.equal(T1[:, written], T2[:, written])
+    for p in (0, P - 1):
+        ld = g.n_pad - p * 512
+        Lpp = torch.tril(a[g.panel_slice(p)].view(512, ld).t()[:512, :])
+        inv_pp = torch.where(written, T1[p], torch.zeros((), dtype=torch.float64, device="cuda"))
+        inv_pp = torch.tril(inv_pp)
+        err = (inv_pp @ Lpp - torch.eye(512, dtype=torch.float64, device="cuda")).abs().max().item()
+        assert err <= 1e-11, (p, err)
     ctx.close()
 
 
 @pytest.mark.parametrize("n,reps", [(2100, 1), (600, 1), (9100, 2)])
 def test_solve_in_panel_steps_is_bit_identical(n, reps):
-    """gprc_dev_trsv (the whole solve) against gprc_dev_trsv_step, the per-panel form the multi-rank sweep runs beside the
-    factorisation: every word equal.  n = 600: two panels; n = 9100: 18 panels.  (The alternative whole-solve kernels --
-    GPRC_TRSV=chain, one launch per panel, and GPRC_TRSV=flag, one launch per solve -- are checked the same way in
-    test_flag_trsv_in_a_fresh_process.)"""
+    """gprc_dev_trsv (the whole solve: one launch per panel, the diagonal step through the explicit inverses of the diagonal
+    blocks, spread over 16 workgroups of the panel's launch) against gprc_dev_trsv_step, the per-panel form the multi-rank sweep
+    runs beside the factorisation: every word equal.  n = 600: two panels; n = 9100: 18 panels.  And it is a solve."""
     L, ctx, g, a = _filled(n, seed=32)
     w, info = _new(g)
-    nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr()))
+    inv = _new_inv(g)
+    nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr(), inv.data_ptr()))
     rng = np.random.default_rng(1)
     b0 = torch.from_numpy(np.concatenate([rng.normal(size=n), np.zeros(g.n_pad - n)])).cuda()
     work = torch.zeros(g.trsv_work, dtype=torch.float64, device="cuda")
+    work2 = torch.zeros(g.trsv_work, dtype=torch.float64, device="cuda")
     for transpose in (0, 1):
         steps = b0.clone()
         order = range(g.P) if not transpose else range(g.P - 1, -1, -1)
         for p in order:
-            nat.check(L.gprc_dev_trsv_step(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, steps.data_ptr(), transpose, p))
+            nat.check(L.gprc_dev_trsv_step(ctx.handle, a.data_ptr(), inv.data_ptr(), g.n_pad, steps.data_ptr(), transpose, p, work2.data_ptr()))
         for _ in range(reps):
             whole = b0.clone()
-            nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, whole.data_ptr(), transpose, work.data_ptr()))
+            nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), inv.data_ptr(), g.n_pad, whole.data_ptr(), transpose, work.data_ptr()))
             torch.cuda.synchronize()
             assert torch.equal(whole, steps)
     # and it is a solve: L (L^T x) = b
     x = b0.clone()
-    nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, x.data_ptr(), 0, work.data_ptr()))
-    nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, x.data_ptr(), 1, work.data_ptr()))
+    nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), inv.data_ptr(), g.n_pad, x.data_ptr(), 0, work.data_ptr()))
+    nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), inv.data_ptr(), g.n_pad, x.data_ptr(), 1, work.data_ptr()))
     torch.cuda.synchronize()
     from oracle import oracle as orc
     Xh = np.random.default_rng(32).uniform(-1, 1, (n, 3))
     Kh = orc.kernel_matrix(orc.SQREXP, [0.6], Xh.T, Xh.T) + 0.1 * np.eye(n)
     assert np.max(np.abs(Kh @ x.cpu().numpy()[:n] - b0.cpu().numpy()[:n])) <= 1e-10 * np.abs(b0.cpu().numpy()).max() * n
+    with pytest.raises(nat.GprcError, match="bad arguments"):
+        nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), NULL, g.n_pad, x.data_ptr(), 0, work.data_ptr()))
     ctx.close()
-
-
-def test_flag_trsv_in_a_fresh_process():
-    """The single-launch strip solve (GPRC_TRSV=flag; not the default -- it measured slower, see kernels_vec.hip) stays
-    bit-identical to the per-panel steps: checked in a child process, because the switch is read once per process."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "import numpy as np, torch\n"
-        "import test_gpu_device_level as T\n"
-        "from gprc_amd import _native as nat\n"
-        "for n, reps in ((2100, 2), (9100, 4)):\n"
-        "    L, ctx, g, a = T._filled(n, seed=32)\n"
-        "    w, info = T._new(g)\n"
-        "    nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr()))\n"
-        "    b0 = torch.from_numpy(np.concatenate([np.random.default_rng(1).normal(size=n), np.zeros(g.n_pad - n)])).cuda()\n"
-        "    work = torch.zeros(g.trsv_work, dtype=torch.float64, device='cuda')\n"
-        "    for tr in (0, 1):\n"
-        "        steps = b0.clone()\n"
-        "        for p in (range(g.P) if not tr else range(g.P - 1, -1, -1)):\n"
-        "            nat.check(L.gprc_dev_trsv_step(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, steps.data_ptr(), tr, p))\n"
-        "        for _ in range(reps):\n"
-        "            whole = b0.clone()\n"
-        "            nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, whole.data_ptr(), tr, work.data_ptr()))\n"
-        "            torch.cuda.synchronize()\n"
-        "            assert torch.equal(whole, steps), (n, tr)\n"
-        "    ctx.close()\n"
-        "print('FLAG-TRSV-OK')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    for mode in ("flag", "chain"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GPRC_TRSV=mode), capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0 and "FLAG-TRSV-OK" in r.stdout, (mode, r.stderr[-2000:])
 
 
 def test_k_chunked_left_looking_passes_are_bit_identical():

@@ -26,7 +26,7 @@ for n in [int(a) for a in sys.argv[1:]] or [8192, 16384]:
     for rep in range(6):
         a.copy_(K); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr()))
+        nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr(), None))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if rep: best = min(best, dt)

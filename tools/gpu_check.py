@@ -119,13 +119,15 @@ def main():
         ypad[:n] = y
         b = torch.from_numpy(ypad.copy()).to(dev)
         work = torch.zeros(L.gprc_trsv_work_size(n_pad), dtype=torch.float64, device=dev)
+        inv = torch.zeros(L.gprc_solve_inv_size(n_pad), dtype=torch.float64, device=dev)
         torch.cuda.synchronize()
-        nat.check(L.gprc_dev_trsv(ctx.handle, packed.data_ptr(), winv.data_ptr(), n_pad, b.data_ptr(), 0, work.data_ptr()))
+        nat.check(L.gprc_dev_solve_prepare(ctx.handle, packed.data_ptr(), winv.data_ptr(), n_pad, inv.data_ptr(), 0, P))
+        nat.check(L.gprc_dev_trsv(ctx.handle, packed.data_ptr(), inv.data_ptr(), n_pad, b.data_ptr(), 0, work.data_ptr()))
         ctx.synchronize()
         import scipy.linalg as sl
         z = sl.solve_triangular(Lref, ypad, lower=True)
         report(f"trsv forward n={n}", b.cpu().numpy(), z, 1e-11)
-        nat.check(L.gprc_dev_trsv(ctx.handle, packed.data_ptr(), winv.data_ptr(), n_pad, b.data_ptr(), 1, work.data_ptr()))
+        nat.check(L.gprc_dev_trsv(ctx.handle, packed.data_ptr(), inv.data_ptr(), n_pad, b.data_ptr(), 1, work.data_ptr()))
         ctx.synchronize()
         report(f"trsv backward n={n}", b.cpu().numpy(), sl.solve_triangular(Lref.T, z, lower=False), 1e-11)
         # cross fill + solve_rows + reductions
