@@ -439,9 +439,10 @@ int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv,
   // GPRC_LOOKAHEAD1=0/1 forces the choice; default: look-ahead up to n_pad = 24576
   static const int la_env = [] { const char* e = std::getenv("GPRC_LOOKAHEAD1"); return e ? std::atoi(e) : -1; }();
   static const bool panel_steps = [] { const char* e = std::getenv("GPRC_PANEL"); return e && std::strcmp(e, "steps") == 0; }();
-  // GPRC_SERVICE=0 turns the factor service off; it runs up to n_pad = 24576 (beyond that the grouped left-looking schedule wins)
+  // GPRC_SERVICE=0 turns the factor service off, =1 forces it at every size; by default it runs up to n_pad = 24576 (beyond that the
+  // grouped left-looking schedule wins)
   static const int sv_env = [] { const char* e = std::getenv("GPRC_SERVICE"); return e ? std::atoi(e) : -1; }();
-  if (!mode && !panel_steps && P >= 2 && la_env < 0 && n_pad <= 24576 && sv_env != 0) return factor_all_service(ctx, packed, n_pad, winv, info_dev, inv);
+  if (!mode && !panel_steps && P >= 2 && la_env < 0 && (sv_env == 1 || (sv_env < 0 && n_pad <= 24576))) return factor_all_service(ctx, packed, n_pad, winv, info_dev, inv);
   if (!mode && !panel_steps && P >= 2 && (la_env == 1 || (la_env < 0 && n_pad <= 24576))) {
     GPRC_TRY(factor_all_lookahead(ctx, packed, n_pad, winv, info_dev));
     return inv ? launch_inv512(s, packed, n_pad, winv, inv, 0, P) : 0;

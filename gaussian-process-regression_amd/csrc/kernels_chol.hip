@@ -255,8 +255,12 @@ __device__ __forceinline__ void potf2_phase_c_block(double* S, const double* Wd,
 
 // the body: NW waves (16: the stand-alone kernel; 8: the factor role of panel_fused_kernel), sm = PB_SMEM_DOUBLES doubles
 // of LDS.  Which wave computes a 16x16 block has no influence on the block's arithmetic: same bits for any NW.
+// ptr (may be null; GPRC_POTF2_TRACE): s_memrealtime stamps of thread 0 -- [0] entry, [1] block loaded, [2] first 16x16 sweep done,
+// [3 + 2 s] / [4 + 2 s] after the two barriers of step s, [19] exit (stores issued).  Measurement only.
+#define POTF2_STAMP(k) do { if (ptr && threadIdx.x == 0) ptr[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 template <int NW>
-__device__ __forceinline__ void potf2_blocked_body(double* sm, double* A, int64_t lda, double* winv, int* info, int col0) {
+__device__ __attribute__((noinline)) void potf2_blocked_body(double* sm, double* A, int64_t lda, double* winv, int* info, int col0,
+                                                             unsigned long long* ptr = nullptr) {
   static_assert(NW >= 8, "phase B needs one wave per task: 7 tasks per step");
   constexpr int TYS = NW / 2;          // column groups of the 128-row load / store loops (NW * 64 threads / 128 rows)
   double* S = sm;                      // PB x BLD
@@ -265,13 +269,25 @@ __device__ __forceinline__ void potf2_blocked_body(double* sm, double* A, int64_
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int q = lane >> 4, r = lane & 15;
+  POTF2_STAMP(0);
   {
+    // all the loads of a thread's 128 / TYS columns are issued before the first LDS store (the loop with one conditional load
+    // per iteration took 4 us of a 46-us block); entries above the diagonal are read too -- allocated storage -- and dropped
     const int i = t & 127, ty = t >> 7;
-    for (int c = ty; c < PB; c += TYS) S[i + c * BLD] = (i >= c) ? A[i + (int64_t)c * lda] : 0.0;
+    constexpr int BATCH = 16;                       // loads in flight per thread (32 VGPRs)
+    for (int k0 = 0; k0 < PB / TYS; k0 += BATCH) {
+      double v[BATCH];
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) v[k] = A[i + (int64_t)(ty + TYS * (k0 + k)) * lda];
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) S[i + (ty + TYS * (k0 + k)) * BLD] = (i >= ty + TYS * (k0 + k)) ? v[k] : 0.0;
+    }
   }
   __syncthreads();
+  POTF2_STAMP(1);
   if (wave == 0) diag16(S, Wd2, Wdiag, info, col0);  // phase A of step 0
   __syncthreads();
+  POTF2_STAMP(2);
   for (int s = 0; s < 8; ++s) {
     const int c0 = 16 * s, m = 7 - s;
     const double* Wd = Wd2 + (s & 1) * 256;
@@ -290,6 +306,7 @@ __device__ __forceinline__ void potf2_blocked_body(double* sm, double* A, int64_
       for (int rr = 0; rr < 4; ++rr) S[(16 * J + r) + (c0 + q + 4 * rr) * BLD] = acc[rr];
     }
     __syncthreads();
+    POTF2_STAMP(3 + 2 * s);
     // ---- phase C with look-ahead: m(m+1)/2 Cholesky blocks then m*(s+1) inverse blocks.  Wave 0 takes block 0 -- the
     // next diagonal block (s+1, s+1) -- and goes straight on to phase A of step s+1 (the sequential 16-pivot sweep,
     // the longest single piece of the kernel) while the other waves work through the other blocks; nothing they touch
@@ -304,14 +321,29 @@ __device__ __forceinline__ void potf2_blocked_body(double* sm, double* A, int64_
       for (int b = wave; b < total; b += NW - 1) potf2_phase_c_block(S, Wd, s, c0, m, b, lane, q, r);
     }
     __syncthreads();
+    POTF2_STAMP(4 + 2 * s);
   }
   {
     const int i = t & 127, ty = t >> 7;
-    for (int c = ty; c < PB; c += TYS) {
-      if (i >= c) A[i + (int64_t)c * lda] = S[i + c * BLD];
-      winv[i + c * PB] = (i > c) ? S[c + i * BLD] : (i == c ? Wdiag[i] : 0.0);
+    const double wd = Wdiag[i];
+    constexpr int BATCH = 8;
+    for (int k0 = 0; k0 < PB / TYS; k0 += BATCH) {  // LDS reads of a batch first (S[c + i BLD]: a row walk, stride BLD), then its stores back to back
+      double lv[BATCH], wv[BATCH];
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int c = ty + TYS * (k0 + k);
+        lv[k] = S[i + c * BLD];
+        wv[k] = (i > c) ? S[c + i * BLD] : (i == c ? wd : 0.0);
+      }
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int c = ty + TYS * (k0 + k);
+        if (i >= c) A[i + (int64_t)c * lda] = lv[k];
+        winv[i + c * PB] = wv[k];
+      }
     }
   }
+  POTF2_STAMP(19);
 }
 
 __global__ __launch_bounds__(1024) void potf2_inv_blocked_kernel(double* A, int64_t lda, double* winv, int* info, int col0) {
@@ -901,11 +933,12 @@ __device__ __forceinline__ void gemm_tile_shadow_barriers(int K) {
 
 // The factor role of one panel: 512 threads (8 waves), sm = PB_SMEM_DOUBLES doubles of LDS.
 __device__ __forceinline__ void panel_factor_role(double* sm, double* pan, int64_t ld, double* wp, int* info, int p, PanelSync* sy,
-                                                  unsigned long long* trace) {
+                                                  unsigned long long* trace, unsigned long long* ptrace = nullptr) {
   const int t = threadIdx.x, team = t >> 8, tid = t & 255;
   PANEL_STAMP(0);
   for (int j = 0; j < TPP; ++j) {
-    potf2_blocked_body<8>(sm, pan + (int64_t)j * NBI + (int64_t)j * NBI * ld, ld, wp + (int64_t)j * NBI * NBI, info, p * NB + j * NBI);
+    potf2_blocked_body<8>(sm, pan + (int64_t)j * NBI + (int64_t)j * NBI * ld, ld, wp + (int64_t)j * NBI * NBI, info, p * NB + j * NBI,
+                          (ptrace && j == 1) ? ptrace : nullptr);
     PANEL_STAMP(1 + 6 * j);
     panel_flag_publish(&sy->W[j]);               // (its vmcnt(0) + barrier also make L(j,j) / Winv_j visible to this workgroup's own DMA)
     PANEL_STAMP(2 + 6 * j);
@@ -975,7 +1008,7 @@ __device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int6
 }
 
 __global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_t n_pad, int p, double* winv, int* info, PanelSync* sy,
-                                                          unsigned long long* trace) {
+                                                          unsigned long long* trace, int potf2_trace) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int sh_id;
   const int t = threadIdx.x;
@@ -988,7 +1021,7 @@ __global__ __launch_bounds__(512) void panel_fused_kernel(double* packed, int64_
   const int S = (int)(ld / 128);
   const int team = t >> 8, tid = t & 255;
   if (id == 0) {                                   // ---- factor role: the critical chain
-    panel_factor_role(sm, pan, ld, wp, info, p, sy, trace);
+    panel_factor_role(sm, pan, ld, wp, info, p, sy, potf2_trace ? nullptr : trace, potf2_trace ? trace : nullptr);
     return;
   }
   int s;
@@ -1302,7 +1335,9 @@ int launch_panel_fused(hipStream_t s, double* packed, int64_t n_pad, int64_t p, 
   // gprc_prof_panel_trace).  Measurement only.
   static const long long trace_p = [] { const char* e = std::getenv("GPRC_PANEL_TRACE"); return e ? std::atoll(e) : -1LL; }();
   unsigned long long* trace = (trace_p == p) ? reinterpret_cast<unsigned long long*>(static_cast<char*>(sync16) + 64) : nullptr;
-  hipLaunchKernelGGL(panel_fused_kernel, dim3(grid), dim3(512), smem, s, packed, n_pad, (int)p, winv, info_dev, reinterpret_cast<PanelSync*>(sync16), trace);
+  static const int potf2_trace = std::getenv("GPRC_POTF2_TRACE") != nullptr;   // the stamps are those of the SECOND diagonal block's potf2 instead
+  hipLaunchKernelGGL(panel_fused_kernel, dim3(grid), dim3(512), smem, s, packed, n_pad, (int)p, winv, info_dev, reinterpret_cast<PanelSync*>(sync16), trace,
+                     potf2_trace);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

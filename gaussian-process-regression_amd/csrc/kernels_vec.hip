@@ -54,17 +54,20 @@ __device__ __forceinline__ double wave_sum(double s) {
   return s;
 }
 
-struct TrsvGate { int done; int failed; };   // one per panel, zeroed before the panel's launch
+struct TrsvGate { int done; int near; };   // one per panel, zeroed before the solve: diagonal workgroups that have published x_p; near-row
+                                           // workgroups of the previous panel's launch that have finished (whole-solve form only)
 constexpr int TRSV_DIAG_WGS = 16;
 constexpr int TRSV_DIAG_ROWS = NB / TRSV_DIAG_WGS;   // 32
+constexpr int TRSV_NEAR_FWD = NB / 128;              // workgroups of a forward launch that cover the next panel's 512 rows
+constexpr int TRSV_NEAR_BWD = NB / 64;               // workgroups of a backward launch that cover the previous panel's 512 columns
 
 // the whole workgroup calls it; returns false on a timeout
-__device__ __forceinline__ bool trsv_gate_wait(TrsvGate* g, int need, int* sh) {
+__device__ __forceinline__ bool trsv_count_wait(int* ctr, int need, int* sh) {
   if (threadIdx.x == 0) {
     int spins = 0, ok = 1;
-    while (__hip_atomic_load(&g->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 24)) { __hip_atomic_store(&g->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+      if (++spins > (1 << 24)) { ok = 0; break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -73,13 +76,13 @@ __device__ __forceinline__ bool trsv_gate_wait(TrsvGate* g, int need, int* sh) {
   __syncthreads();
   return *sh != 0;
 }
-__device__ __forceinline__ void trsv_gate_arrive(TrsvGate* g) {   // the whole workgroup calls it
+__device__ __forceinline__ void trsv_count_arrive(int* ctr) {   // the whole workgroup calls it
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(&g->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -105,115 +108,167 @@ __device__ __forceinline__ double gemvt_column_dot(const double* col, const doub
   return wave_sum(s);
 }
 
-// Forward step of panel p.  512 threads.  Blocks [0, 16): x_p rows 32 i .. 32 i + 31 (a wave: 4 rows; a lane: 8 consecutive
-// columns of each row, ascending, then the wave tree).  Blocks >= 16: 128 rows below the panel x 4 column groups.
-__global__ __launch_bounds__(512) void trsv_fwd_kernel(const double* packed, const double* inv, int64_t n_pad, int p, double* b, double* zbuf,
-                                                       TrsvGate* gate) {
-  __shared__ double xs[NB];
-  __shared__ double red[4][128];
-  __shared__ int sh_ok;
-  const int t = threadIdx.x;
+// ---- forward pieces (512 threads) ----
+// diagonal role `role` (0..15) of panel p: x_p rows 32 role .. 32 role + 31 (a wave: 4 rows; a lane: 8 consecutive columns of each
+// row, ascending, then the wave tree) -> zbuf, gate; b_p itself receives x_p once every diagonal workgroup has read it
+__device__ __forceinline__ void trsv_fwd_diag(const double* inv, int p, double* b, double* zbuf, TrsvGate* gate, int role, double* xs, int* sh_ok) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   double* bp = b + (int64_t)p * NB;
   double* zp = zbuf + (int64_t)p * NB;
-  if (blockIdx.x < TRSV_DIAG_WGS) {
-    const int lane = t & 63, w = t >> 6;
-    const int r0 = TRSV_DIAG_ROWS * (int)blockIdx.x + 4 * w;
-    const double* T = inv + (int64_t)p * NB * NB + (int64_t)r0 * NB + 8 * lane;
-    double tv[4][8];
+  const int r0 = TRSV_DIAG_ROWS * role + 4 * w;
+  const double* T = inv + (int64_t)p * NB * NB + (int64_t)r0 * NB + 8 * lane;
+  double tv[4][8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 4; ++k)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) tv[k][e] = (8 * lane + e <= r0 + k) ? T[(int64_t)k * NB + e] : 0.0;   // the loads fly while b_p is staged
-    for (int c = t; c < NB; c += 512) xs[c] = bp[c];
-    __syncthreads();
-    double v[4];
+    for (int e = 0; e < 8; ++e) tv[k][e] = (8 * lane + e <= r0 + k) ? T[(int64_t)k * NB + e] : 0.0;   // the loads fly while b_p is staged
+  for (int c = t; c < NB; c += 512) xs[c] = bp[c];
+  __syncthreads();
+  double v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      double s = 0.0;
+  for (int k = 0; k < 4; ++k) {
+    double s = 0.0;
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (8 * lane + e <= r0 + k) s = fma(tv[k][e], xs[8 * lane + e], s);
-      v[k] = wave_sum(s);
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) zp[r0 + k] = v[k];
-    }
-    trsv_gate_arrive(gate);
-    // b_p itself receives x_p once every diagonal workgroup has read it
-    const bool ok = trsv_gate_wait(gate, TRSV_DIAG_WGS, &sh_ok);
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) bp[r0 + k] = ok ? v[k] : __builtin_nan("");
-    }
-    return;
+    for (int e = 0; e < 8; ++e)
+      if (8 * lane + e <= r0 + k) s = fma(tv[k][e], xs[8 * lane + e], s);
+    v[k] = wave_sum(s);
   }
-  const int i = t & 127, g = t >> 7;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) zp[r0 + k] = v[k];
+  }
+  trsv_count_arrive(&gate->done);
+  const bool ok = trsv_count_wait(&gate->done, TRSV_DIAG_WGS, sh_ok);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bp[r0 + k] = ok ? v[k] : __builtin_nan("");
+  }
+}
+
+// 128 rows starting at `row0` (global row index) x the NB columns of panel p, 4 column groups: b[row] -= L[row, panel p] x_p
+__device__ __forceinline__ void trsv_fwd_rows(const double* packed, int64_t n_pad, int p, double* b, const double* zbuf, int64_t row0, bool ok,
+                                              double* xs, double (*red)[128]) {
+  const int t = threadIdx.x, i = t & 127, g = t >> 7;
   const int64_t ld = panel_ld(n_pad, p);
-  const int64_t row = (int64_t)(p + 1) * NB + (int64_t)(blockIdx.x - TRSV_DIAG_WGS) * 128 + i;
+  const int64_t row = row0 + i;
   const double* Lr = packed + panel_offset(n_pad, p) + (row - (int64_t)p * NB) + (int64_t)(g * (NB / 4)) * ld;
-  const bool ok = trsv_gate_wait(gate, TRSV_DIAG_WGS, &sh_ok);
-  for (int c = t; c < NB; c += 512) xs[c] = zp[c];
+  for (int c = t; c < NB; c += 512) xs[c] = zbuf[(int64_t)p * NB + c];
   __syncthreads();
   red[g][i] = gemv_group_partial(Lr, ld, xs + g * (NB / 4));
   __syncthreads();
   if (g == 0) b[row] = ok ? b[row] - ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) : __builtin_nan("");
 }
 
-// Backward step of panel p.  512 threads.  Blocks [0, 16): x_p columns 32 i .. 32 i + 31 (thread = column x one of 16 row
-// groups r = g, g + 16, ..; the 16 partials of a column are added in group order).  Blocks >= 16: (earlier panel q, 64 of its
-// columns): one wave per column at a time, 8 columns per wave.
-__global__ __launch_bounds__(512) void trsv_bwd_kernel(const double* packed, const double* inv, int64_t n_pad, int p, double* x, double* zbuf,
-                                                       TrsvGate* gate) {
+// Forward launch of panel p.
+// FUSED = false (gprc_dev_trsv_step): blocks [0, 16) the diagonal step of panel p; blocks >= 16: 128 rows below the panel each, after
+//   the gate.
+// FUSED = true (inside a whole solve; x_p is already in zbuf -- the previous launch left it): blocks [0, 4) the rows of panel p + 1,
+//   counting into that panel's `near`; blocks [4, 20) the DIAGONAL STEP OF PANEL p + 1, which so runs while the other blocks
+//   (>= 20: the rows behind panel p + 1) are still streaming; nobody waits for anything but those four.
+template <bool FUSED>
+__global__ __launch_bounds__(512) void trsv_fwd_kernel(const double* packed, const double* inv, int64_t n_pad, int p, double* b, double* zbuf,
+                                                       TrsvGate* gates) {
   __shared__ double xs[NB];
-  __shared__ double red[16][TRSV_DIAG_ROWS];
+  __shared__ double red[4][128];
   __shared__ int sh_ok;
+  const int bid = (int)blockIdx.x;
+  if constexpr (!FUSED) {
+    if (bid < TRSV_DIAG_WGS) { trsv_fwd_diag(inv, p, b, zbuf, gates + p, bid, xs, &sh_ok); return; }
+    const bool ok = trsv_count_wait(&gates[p].done, TRSV_DIAG_WGS, &sh_ok);
+    trsv_fwd_rows(packed, n_pad, p, b, zbuf, (int64_t)(p + 1) * NB + (int64_t)(bid - TRSV_DIAG_WGS) * 128, ok, xs, red);
+  } else {
+    if (bid < TRSV_NEAR_FWD) {
+      trsv_fwd_rows(packed, n_pad, p, b, zbuf, (int64_t)(p + 1) * NB + (int64_t)bid * 128, true, xs, red);
+      trsv_count_arrive(&gates[p + 1].near);
+    } else if (bid < TRSV_NEAR_FWD + TRSV_DIAG_WGS) {
+      const bool ok = trsv_count_wait(&gates[p + 1].near, TRSV_NEAR_FWD, &sh_ok);
+      trsv_fwd_diag(inv, p + 1, b, zbuf, gates + p + 1, bid - TRSV_NEAR_FWD, xs, &sh_ok);
+      if (!ok && threadIdx.x < TRSV_DIAG_ROWS) b[(int64_t)(p + 1) * NB + TRSV_DIAG_ROWS * (bid - TRSV_NEAR_FWD) + threadIdx.x] = __builtin_nan("");
+    } else {
+      trsv_fwd_rows(packed, n_pad, p, b, zbuf, (int64_t)(p + 2) * NB + (int64_t)(bid - TRSV_NEAR_FWD - TRSV_DIAG_WGS) * 128, true, xs, red);
+    }
+  }
+}
+
+// ---- backward pieces (512 threads) ----
+// diagonal role `role` of panel p: x_p columns 32 role .. 32 role + 31 (thread = column x one of 16 row groups r = g, g + 16, ..;
+// the 16 partials of a column are added in group order)
+__device__ __forceinline__ void trsv_bwd_diag(const double* inv, int p, double* x, double* zbuf, TrsvGate* gate, int role, double* xs,
+                                              double (*red)[TRSV_DIAG_ROWS], int* sh_ok) {
   const int t = threadIdx.x;
   double* xp = x + (int64_t)p * NB;
   double* zp = zbuf + (int64_t)p * NB;
-  if (blockIdx.x < TRSV_DIAG_WGS) {
-    const int cc = t & (TRSV_DIAG_ROWS - 1), g = t >> 5;
-    const int c = TRSV_DIAG_ROWS * (int)blockIdx.x + cc;
-    const double* T = inv + (int64_t)p * NB * NB + c;        // T[c + r NB] = inv(L_pp)[r, c]
-    double tv[NB / 16];
+  const int cc = t & (TRSV_DIAG_ROWS - 1), g = t >> 5;
+  const int c = TRSV_DIAG_ROWS * role + cc;
+  const double* T = inv + (int64_t)p * NB * NB + c;        // T[c + r NB] = inv(L_pp)[r, c]
+  double tv[NB / 16];
 #pragma unroll
-    for (int k = 0; k < NB / 16; ++k) {
-      const int r = g + 16 * k;
-      tv[k] = (r >= c) ? T[(int64_t)r * NB] : 0.0;
-    }
-    for (int r = t; r < NB; r += 512) xs[r] = xp[r];
-    __syncthreads();
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < NB / 16; ++k) {
-      const int r = g + 16 * k;
-      if (r >= c) s = fma(tv[k], xs[r], s);
-    }
-    red[g][cc] = s;
-    __syncthreads();
-    double v = 0.0;
-    if (g == 0) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v += red[q][cc];
-      zp[c] = v;
-    }
-    trsv_gate_arrive(gate);
-    const bool ok = trsv_gate_wait(gate, TRSV_DIAG_WGS, &sh_ok);
-    if (g == 0) xp[c] = ok ? v : __builtin_nan("");
-    return;
+  for (int k = 0; k < NB / 16; ++k) {
+    const int r = g + 16 * k;
+    tv[k] = (r >= c) ? T[(int64_t)r * NB] : 0.0;
   }
-  const int lane = t & 63, w = t >> 6;
-  const int cb = (int)blockIdx.x - TRSV_DIAG_WGS, q = cb / (NB / 64), cg = cb % (NB / 64);
+  for (int r = t; r < NB; r += 512) xs[r] = xp[r];
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < NB / 16; ++k) {
+    const int r = g + 16 * k;
+    if (r >= c) s = fma(tv[k], xs[r], s);
+  }
+  red[g][cc] = s;
+  __syncthreads();
+  double v = 0.0;
+  if (g == 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += red[q][cc];
+    zp[c] = v;
+  }
+  trsv_count_arrive(&gate->done);
+  const bool ok = trsv_count_wait(&gate->done, TRSV_DIAG_WGS, sh_ok);
+  if (g == 0) xp[c] = ok ? v : __builtin_nan("");
+}
+
+// 64 columns (cg) of the earlier panel q: x[q NB + c] -= L[panel-p rows, that column]^T x_p; one wave per column at a time
+__device__ __forceinline__ void trsv_bwd_cols(const double* packed, int64_t n_pad, int p, double* x, const double* zbuf, int q, int cg, bool ok, double* xs) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int64_t ldq = panel_ld(n_pad, q);
   const double* blk = packed + panel_offset(n_pad, q) + (int64_t)(p - q) * NB;  // rows of panel p inside panel q
-  const bool ok = trsv_gate_wait(gate, TRSV_DIAG_WGS, &sh_ok);
-  for (int r = t; r < NB; r += 512) xs[r] = zp[r];
+  for (int r = t; r < NB; r += 512) xs[r] = zbuf[(int64_t)p * NB + r];
   __syncthreads();
 #pragma unroll 2
   for (int k = 0; k < 8; ++k) {
     const int c = cg * 64 + w * 8 + k;
     const double s = gemvt_column_dot(blk + (int64_t)c * ldq, xs, lane);
     if (lane == 0) x[(int64_t)q * NB + c] = ok ? x[(int64_t)q * NB + c] - s : __builtin_nan("");
+  }
+}
+
+// Backward launch of panel p; FUSED as above with "previous panel" = p - 1: blocks [0, 8) its 512 columns (-> near), blocks [8, 24)
+// its diagonal step, blocks >= 24 the panels q < p - 1.
+template <bool FUSED>
+__global__ __launch_bounds__(512) void trsv_bwd_kernel(const double* packed, const double* inv, int64_t n_pad, int p, double* x, double* zbuf,
+                                                       TrsvGate* gates) {
+  __shared__ double xs[NB];
+  __shared__ double red[16][TRSV_DIAG_ROWS];
+  __shared__ int sh_ok;
+  const int bid = (int)blockIdx.x;
+  if constexpr (!FUSED) {
+    if (bid < TRSV_DIAG_WGS) { trsv_bwd_diag(inv, p, x, zbuf, gates + p, bid, xs, red, &sh_ok); return; }
+    const int cb = bid - TRSV_DIAG_WGS;
+    const bool ok = trsv_count_wait(&gates[p].done, TRSV_DIAG_WGS, &sh_ok);
+    trsv_bwd_cols(packed, n_pad, p, x, zbuf, cb / (NB / 64), cb % (NB / 64), ok, xs);
+  } else {
+    if (bid < TRSV_NEAR_BWD) {
+      trsv_bwd_cols(packed, n_pad, p, x, zbuf, p - 1, bid, true, xs);
+      trsv_count_arrive(&gates[p - 1].near);
+    } else if (bid < TRSV_NEAR_BWD + TRSV_DIAG_WGS) {
+      const bool ok = trsv_count_wait(&gates[p - 1].near, TRSV_NEAR_BWD, &sh_ok);
+      trsv_bwd_diag(inv, p - 1, x, zbuf, gates + p - 1, bid - TRSV_NEAR_BWD, xs, red, &sh_ok);
+      if (!ok && threadIdx.x < TRSV_DIAG_ROWS) x[(int64_t)(p - 1) * NB + TRSV_DIAG_ROWS * (bid - TRSV_NEAR_BWD) + threadIdx.x] = __builtin_nan("");
+    } else {
+      const int cb = bid - TRSV_NEAR_BWD - TRSV_DIAG_WGS;
+      trsv_bwd_cols(packed, n_pad, p, x, zbuf, cb / (NB / 64), cb % (NB / 64), true, xs);
+    }
   }
 }
 
@@ -414,37 +469,60 @@ int64_t rowreduce_splits(int64_t cols) { return (cols + RR_COLS - 1) / RR_COLS; 
 // work (gprc_trsv_work_size(n_pad) doubles): x_p staging (n_pad doubles) and one gate per panel behind it
 static inline TrsvGate* trsv_gates(double* work, int64_t n_pad) { return reinterpret_cast<TrsvGate*>(work + n_pad); }
 
-static int launch_trsv_panel(hipStream_t s, const double* packed, const double* inv, int64_t n_pad, double* b, int transpose, int p, double* work) {
-  TrsvGate* gate = trsv_gates(work, n_pad) + p;
+// one panel step of the solve: x_p, then its contribution to the rest of the right-hand side (one launch)
+int launch_trsv_step(hipStream_t s, const double* packed, const double* inv, int64_t n_pad, double* b, int transpose, int p, double* work) {
+  const int P = (int)(n_pad / NB);
+  if (p < 0 || p >= P) { set_error("trsv_step: panel out of range"); return GPRC_ERR_ARG; }
+  if (!inv || !work) { set_error("trsv_step: the explicit diagonal inverses and the work buffer are required"); return GPRC_ERR_ARG; }
+  TrsvGate* gates = trsv_gates(work, n_pad);
+  GPRC_HIP(hipMemsetAsync(gates + p, 0, sizeof(TrsvGate), s));
   if (!transpose) {
     const int64_t below = n_pad - (int64_t)(p + 1) * NB;
-    hipLaunchKernelGGL(trsv_fwd_kernel, dim3((unsigned)(TRSV_DIAG_WGS + below / 128)), dim3(512), 0, s, packed, inv, n_pad, p, b, work, gate);
+    hipLaunchKernelGGL(trsv_fwd_kernel<false>, dim3((unsigned)(TRSV_DIAG_WGS + below / 128)), dim3(512), 0, s, packed, inv, n_pad, p, b, work, gates);
   } else {
-    hipLaunchKernelGGL(trsv_bwd_kernel, dim3((unsigned)(TRSV_DIAG_WGS + p * (NB / 64))), dim3(512), 0, s, packed, inv, n_pad, p, b, work, gate);
+    hipLaunchKernelGGL(trsv_bwd_kernel<false>, dim3((unsigned)(TRSV_DIAG_WGS + p * (NB / 64))), dim3(512), 0, s, packed, inv, n_pad, p, b, work, gates);
   }
   GPRC_LAUNCH_CHECK();
   return 0;
 }
 
-// one panel step of the solve: x_p, then its contribution to the rest of the right-hand side
-int launch_trsv_step(hipStream_t s, const double* packed, const double* inv, int64_t n_pad, double* b, int transpose, int p, double* work) {
-  const int P = (int)(n_pad / NB);
-  if (p < 0 || p >= P) { set_error("trsv_step: panel out of range"); return GPRC_ERR_ARG; }
-  if (!inv || !work) { set_error("trsv_step: the explicit diagonal inverses and the work buffer are required"); return GPRC_ERR_ARG; }
-  GPRC_HIP(hipMemsetAsync(trsv_gates(work, n_pad) + p, 0, sizeof(TrsvGate), s));
-  return launch_trsv_panel(s, packed, inv, n_pad, b, transpose, p, work);
-}
-
-// the whole solve: P launches
+// The whole solve: P launches.  The first is the diagonal step of the first panel alone; launch p then carries the product of
+// panel p AND the diagonal step of the next panel (fused form): that step -- two dependent hand-offs -- runs beside the streaming of
+// the product instead of in front of the next launch.  Element by element the arithmetic is that of the per-step launches
+// (the same device functions): identical bits.  GPRC_TRSV=steps runs the per-step launches instead.
 int launch_trsv(hipStream_t s, const double* packed, const double* inv, int64_t n_pad, double* b, int transpose, double* work) {
   const int P = (int)(n_pad / NB);
   if (!inv || !work) { set_error("trsv: the explicit diagonal inverses and the work buffer are required"); return GPRC_ERR_ARG; }
   ProfScope ps(s, PK_TRSV, (double)n_pad * n_pad, 8.0 * 0.5 * n_pad * n_pad);
-  GPRC_HIP(hipMemsetAsync(trsv_gates(work, n_pad), 0, sizeof(TrsvGate) * (size_t)P, s));
-  if (!transpose)
-    for (int p = 0; p < P; ++p) GPRC_TRY(launch_trsv_panel(s, packed, inv, n_pad, b, 0, p, work));
-  else
-    for (int p = P - 1; p >= 0; --p) GPRC_TRY(launch_trsv_panel(s, packed, inv, n_pad, b, 1, p, work));
+  TrsvGate* gates = trsv_gates(work, n_pad);
+  GPRC_HIP(hipMemsetAsync(gates, 0, sizeof(TrsvGate) * (size_t)P, s));
+  static const bool steps = [] { const char* e = std::getenv("GPRC_TRSV"); return e && std::strcmp(e, "steps") == 0; }();
+  if (!transpose) {
+    if (steps) {
+      for (int p = 0; p < P; ++p) {
+        const int64_t below = n_pad - (int64_t)(p + 1) * NB;
+        hipLaunchKernelGGL(trsv_fwd_kernel<false>, dim3((unsigned)(TRSV_DIAG_WGS + below / 128)), dim3(512), 0, s, packed, inv, n_pad, p, b, work, gates);
+      }
+    } else {
+      hipLaunchKernelGGL(trsv_fwd_kernel<false>, dim3(TRSV_DIAG_WGS), dim3(512), 0, s, packed, inv, n_pad, 0, b, work, gates);
+      for (int p = 0; p + 1 < P; ++p) {
+        const int64_t behind = n_pad - (int64_t)(p + 2) * NB;
+        hipLaunchKernelGGL(trsv_fwd_kernel<true>, dim3((unsigned)(TRSV_NEAR_FWD + TRSV_DIAG_WGS + behind / 128)), dim3(512), 0, s, packed, inv, n_pad, p, b,
+                           work, gates);
+      }
+    }
+  } else {
+    if (steps) {
+      for (int p = P - 1; p >= 0; --p)
+        hipLaunchKernelGGL(trsv_bwd_kernel<false>, dim3((unsigned)(TRSV_DIAG_WGS + p * (NB / 64))), dim3(512), 0, s, packed, inv, n_pad, p, b, work, gates);
+    } else {
+      hipLaunchKernelGGL(trsv_bwd_kernel<false>, dim3(TRSV_DIAG_WGS), dim3(512), 0, s, packed, inv, n_pad, P - 1, b, work, gates);
+      for (int p = P - 1; p >= 1; --p)
+        hipLaunchKernelGGL(trsv_bwd_kernel<true>, dim3((unsigned)(TRSV_NEAR_BWD + TRSV_DIAG_WGS + (p - 1) * (NB / 64))), dim3(512), 0, s, packed, inv, n_pad, p,
+                           b, work, gates);
+    }
+  }
+  GPRC_LAUNCH_CHECK();
   return 0;
 }
 
