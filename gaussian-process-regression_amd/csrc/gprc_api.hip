@@ -395,34 +395,27 @@ int factor_all_lookahead(gprc_ctx* ctx, double* packed, int64_t n_pad, double* w
   return 0;
 }
 
-// Right-looking sweep with the FACTOR SERVICE (kernels_chol.hip): the whole dependent chain -- diagonal blocks, the strips around
-// them, the rows of the next diagonal block and that block's update -- runs in ONE persistent ten-workgroup launch on a side
-// stream; the caller's stream carries the ordinary strips and the rest of the trailing update, one launch each per panel, tied to
-// the service by counters.  Same tiles in the same k order: bit-identical.
-int factor_all_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev, double* inv) {
-  hipStream_t s = ctx->stream;
-  const int64_t P = n_pad / NB;
-  if (!ctx->side_stream) {
-    int lo = 0, hi = 0;
-    GPRC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    GPRC_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi));
-  }
-  hipStream_t side = ctx->side_stream;
-  DevMem sync;   // flags of every panel + the ready counters; goes back to the pool when every launch below has been ordered behind it
-  GPRC_TRY(sync.alloc((int64_t)(panel_service_sync_bytes(P) + 7) / 8));
-  GPRC_HIP(hipMemsetAsync(sync.p, 0, panel_service_sync_bytes(P), s));
-  static const bool want_trace = std::getenv("GPRC_SERVICE_TRACE") != nullptr;
-  void* trace = nullptr;
-  if (want_trace && P <= SVC_TRACE_PANELS) {
-    if (!ctx->svc_trace) GPRC_HIP(hipMalloc(&ctx->svc_trace, SVC_TRACE_PANELS * 16 * sizeof(int64_t)));
-    GPRC_HIP(hipMemsetAsync(ctx->svc_trace, 0, SVC_TRACE_PANELS * 16 * sizeof(int64_t), s));
-    trace = ctx->svc_trace;
-  }
-  GPRC_TRY(stream_after(ctx, side, s));                       // the fill, the caller's memset of info and the flag reset precede the service
-  GPRC_TRY(launch_panel_service(side, packed, n_pad, winv, info_dev, sync.p, trace, inv));
-  GPRC_TRY(launch_service_gate(s, n_pad, info_dev, sync.p));  // nothing that waits on the service starts before the service is resident
-  GPRC_TRY(launch_panel_strips(s, packed, n_pad, 0, winv, info_dev, sync.p, trace));      // the later panels' strips ride in the update kernels
-  for (int64_t p = 0; p + 1 < P; ++p) GPRC_TRY(launch_trailing_service(s, packed, n_pad, p, winv, info_dev, sync.p, trace));
+// Lower tiles a group of the left-looking schedule should have at least (see factor_all_async)
+static int64_t want_for(int64_t n_pad) {
+  // below n_pad = 20480 one group -- the plain right-looking sweep under the factor service -- is fastest (measured,
+  // profiles/r02_factor_schedules.txt: n = 16384 30.0 ms against 29.2..32.8 with groups of 1000..6000 tiles); from there on 8192
+  return n_pad < 20480 ? INT64_MAX : 8192;
+}
+
+// One GROUP of panels [g0, g1) with the FACTOR SERVICE (kernels_chol.hip): the group's columns have received every earlier panel
+// (left-looking pass, or g0 = 0); inside the group the sweep is right-looking with the whole dependent chain -- diagonal blocks, the
+// strips around them, the rows of the next diagonal block and that block's update -- in ONE persistent 21-workgroup launch on a side
+// stream; the caller's stream carries the ordinary strips and the rest of the within-group update, one launch per panel, tied to the
+// service by counters.  Same tiles in the same k order: bit-identical.  sync: panel_service_sync_bytes(P), zeroed once per
+// factorisation; launches: service launches on it so far (this one included).
+int factor_group_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev, double* inv, int64_t g0, int64_t g1, void* sync,
+                         void* trace, int launches) {
+  hipStream_t s = ctx->stream, side = ctx->side_stream;
+  GPRC_TRY(stream_after(ctx, side, s));                       // everything the group's first panel needs precedes the service
+  GPRC_TRY(launch_panel_service(side, packed, n_pad, winv, info_dev, sync, trace, inv, g0, g1));
+  GPRC_TRY(launch_service_gate(s, n_pad, info_dev, sync, launches));   // nothing that waits on the service starts before the service is resident
+  GPRC_TRY(launch_panel_strips(s, packed, n_pad, g0, winv, info_dev, sync, trace));        // the later panels' strips ride in the update kernels
+  for (int64_t p = g0; p + 1 < g1; ++p) GPRC_TRY(launch_trailing_service(s, packed, n_pad, p, winv, info_dev, sync, trace, g1));
   GPRC_TRY(stream_after(ctx, s, side));
   return 0;
 }
@@ -432,32 +425,55 @@ int factor_all_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* win
 int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev, double* inv) {
   hipStream_t s = ctx->stream;
   const int64_t P = n_pad / NB;
+  // Groups: the shortest run of panels with >= `want` lower tiles (GPRC_FACTOR=<tiles>, =right: one group); a left-looking tile is
+  // long, so a pass needs many generations of tiles per CU or its ragged last one costs more than the saved prologues.
   const char* mode = std::getenv("GPRC_FACTOR");
-  int64_t want = 8192;
+  int64_t want = want_for(n_pad);
   if (mode && std::strcmp(mode, "right") == 0) want = INT64_MAX;
   else if (mode && std::atoll(mode) > 0) want = std::atoll(mode);
-  // GPRC_LOOKAHEAD1=0/1 forces the choice; default: look-ahead up to n_pad = 24576
+  // GPRC_LOOKAHEAD1=1: the look-ahead-on-streams sweep (superseded); GPRC_PANEL=steps: the launch-per-stage panel kernels;
+  // GPRC_SERVICE=0: one fused launch per panel inside the groups instead of the factor service
   static const int la_env = [] { const char* e = std::getenv("GPRC_LOOKAHEAD1"); return e ? std::atoi(e) : -1; }();
   static const bool panel_steps = [] { const char* e = std::getenv("GPRC_PANEL"); return e && std::strcmp(e, "steps") == 0; }();
-  // GPRC_SERVICE=0 turns the factor service off, =1 forces it at every size; by default it runs up to n_pad = 24576 (beyond that the
-  // grouped left-looking schedule wins)
   static const int sv_env = [] { const char* e = std::getenv("GPRC_SERVICE"); return e ? std::atoi(e) : -1; }();
-  if (!mode && !panel_steps && P >= 2 && la_env < 0 && (sv_env == 1 || (sv_env < 0 && n_pad <= 24576))) return factor_all_service(ctx, packed, n_pad, winv, info_dev, inv);
-  if (!mode && !panel_steps && P >= 2 && (la_env == 1 || (la_env < 0 && n_pad <= 24576))) {
+  if (!mode && !panel_steps && P >= 2 && la_env == 1) {
     GPRC_TRY(factor_all_lookahead(ctx, packed, n_pad, winv, info_dev));
     return inv ? launch_inv512(s, packed, n_pad, winv, inv, 0, P) : 0;
   }
+  const bool service = !panel_steps && sv_env != 0 && P >= 2;
+  DevMem sync;   // flags of every panel + the counters; goes back to the pool when every launch below has been ordered behind it
+  void* trace = nullptr;
+  if (service) {
+    if (!ctx->side_stream) {
+      int lo = 0, hi = 0;
+      GPRC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      GPRC_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi));
+    }
+    GPRC_TRY(sync.alloc((int64_t)(panel_service_sync_bytes(P) + 7) / 8));
+    GPRC_HIP(hipMemsetAsync(sync.p, 0, panel_service_sync_bytes(P), s));
+    static const bool want_trace = std::getenv("GPRC_SERVICE_TRACE") != nullptr;
+    if (want_trace && P <= SVC_TRACE_PANELS) {
+      if (!ctx->svc_trace) GPRC_HIP(hipMalloc(&ctx->svc_trace, SVC_TRACE_PANELS * 16 * sizeof(int64_t)));
+      GPRC_HIP(hipMemsetAsync(ctx->svc_trace, 0, SVC_TRACE_PANELS * 16 * sizeof(int64_t), s));
+      trace = ctx->svc_trace;
+    }
+  }
+  int launches = 0;
   for (int64_t g0 = 0; g0 < P;) {
     int64_t g1 = g0, tiles = 0;
     while (g1 < P && tiles < want) { tiles += (int64_t)TPP * TPP * (P - g1) - TPP * (TPP - 1) / 2; ++g1; }
     GPRC_TRY(launch_trailing_left(s, packed, n_pad, g0, g1));
-    for (int64_t p = g0; p < g1; ++p) {
-      GPRC_TRY(factor_panel(ctx, packed, n_pad, p, winv, info_dev));
-      if (p + 1 < g1) GPRC_TRY(launch_trailing_update(s, packed, n_pad, p, p + 1, g1, 1));
+    if (service) {
+      GPRC_TRY(factor_group_service(ctx, packed, n_pad, winv, info_dev, inv, g0, g1, sync.p, trace, ++launches));
+    } else {
+      for (int64_t p = g0; p < g1; ++p) {
+        GPRC_TRY(factor_panel(ctx, packed, n_pad, p, winv, info_dev));
+        if (p + 1 < g1) GPRC_TRY(launch_trailing_update(s, packed, n_pad, p, p + 1, g1, 1));
+      }
     }
     g0 = g1;
   }
-  return inv ? launch_inv512(s, packed, n_pad, winv, inv, 0, P) : 0;
+  return (inv && !service) ? launch_inv512(s, packed, n_pad, winv, inv, 0, P) : 0;
 }
 
 int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_host, double* inv = nullptr) {

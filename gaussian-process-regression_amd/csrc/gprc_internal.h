@@ -105,12 +105,13 @@ int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t
 // factor service (one-GPU right-looking sweep): the dependent chain of all panels in one persistent launch (side stream) + per panel
 // the ordinary strips and the trailing update without the next diagonal block (caller's stream)
 size_t panel_service_sync_bytes(int64_t P);
-int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync, void* trace, double* inv);
+int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync, void* trace, double* inv,
+                         int64_t p_begin, int64_t p_end);
 // inv (n_pad x NB doubles): per panel the explicit inverse of its NB x NB diagonal block, transposed -- what the vector solves use
 int launch_inv512(hipStream_t s, const double* packed, int64_t n_pad, const double* winv, double* inv, int64_t p_begin, int64_t p_end);
-int launch_service_gate(hipStream_t s, int64_t n_pad, int* info_dev, void* sync);
+int launch_service_gate(hipStream_t s, int64_t n_pad, int* info_dev, void* sync, int launches);
 int launch_panel_strips(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync, void* trace);
-int launch_trailing_service(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync, void* trace);
+int launch_trailing_service(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync, void* trace, int64_t q_end);
 
 // ---- launchers (kernels_vec.hip) ---------------------------------------------------------------
 int launch_trailing_left(hipStream_t s, double* packed, int64_t n_pad, int64_t q_begin, int64_t q_end);

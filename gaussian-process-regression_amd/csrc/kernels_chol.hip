@@ -1138,36 +1138,39 @@ __device__ __forceinline__ void panel_next_diag_role(double* smem, const double*
 // trace (may be null; GPRC_SERVICE_TRACE): 16 s_memrealtime stamps per panel, see gprc_prof_service_trace -- measurement only
 #define SERVICE_STAMP(p, k) do { if (trace && (threadIdx.x & 255) == 0) trace[16 * (p) + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
+// The launch serves the panels [p_begin, p_end) -- a group of the grouped left-looking schedule, or all of them: its first panel is
+// complete when the launch starts; the next diagonal block is updated only inside the group (the panel behind the group receives
+// everything in its left-looking pass, k ascending), the look-ahead strips are solved for every panel that has rows below it.
 __global__ __launch_bounds__(512) void panel_service_kernel(double* packed, int64_t n_pad, double* winv, int* info, PanelSync* sy_base,
-                                                            int* ready, int P, unsigned long long* trace, double* inv) {
+                                                            int* ready, int P, unsigned long long* trace, double* inv, int p_begin, int p_end) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int role = blockIdx.x;
   const int t = threadIdx.x, team = t >> 8, tid = t & 255;
   if (t == 0) __hip_atomic_fetch_add(&ready[3 * P], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident: see service_gate_kernel
   if (role >= 1 && team == 1) return;                // every role but the factor role is one 4-wave team
   if (role >= SERVICE_INV0 && !inv) return;
-  for (int p = 0; p < P; ++p) {
+  for (int p = p_begin; p < p_end; ++p) {
     PanelSync* sy = sy_base + p;
     const int64_t ld = panel_ld(n_pad, p);
     double* pan = packed + panel_offset(n_pad, p);
     double* wp = winv + (int64_t)p * TPP * NBI * NBI;
     if (role <= 2) {
       if (role == 0) SERVICE_STAMP(p, 14);
-      if (p > 0) panel_ready_wait(&ready[p], PANEL_DIAG_TILES, sy, info);
+      if (p > p_begin) panel_ready_wait(&ready[p], PANEL_DIAG_TILES, sy, info);
       if (role == 0) SERVICE_STAMP(p, 0);
       if (role == 0) panel_factor_role(sm, pan, ld, wp, info, p, sy, nullptr);
       else panel_strip_role(sm, pan, ld, wp, info, sy, role + 1, tid, &sy->E[role - 1], 1);
       if (role == 0) SERVICE_STAMP(p, 1);
     } else if (role >= SERVICE_INV0) {
       inv512_row_role(sm, pan, ld, wp, inv + (int64_t)p * NB * NB, role - SERVICE_INV0, tid, sy, info);
-    } else if (p + 1 < P) {
+    } else if (role < SERVICE_D0 ? p + 1 < P : p + 1 < p_end) {
       if (role < SERVICE_D0) {
-        if (p > 0) panel_ready_wait(&ready[P + p], PANEL_LA_TILES, sy, info);
+        if (p > p_begin) panel_ready_wait(&ready[P + p], PANEL_LA_TILES, sy, info);
         if (role == SERVICE_LA0) SERVICE_STAMP(p, 2);
         panel_strip_role(sm, pan, ld, wp, info, sy, TPP + (role - SERVICE_LA0), tid, &sy->LA, 1, sy->E);
         if (role == SERVICE_LA0) SERVICE_STAMP(p, 3);
       } else {
-        if (p > 0) panel_ready_wait(&ready[2 * P + p + 1], PANEL_DIAG_TILES, sy, info);
+        if (p > p_begin) panel_ready_wait(&ready[2 * P + p + 1], PANEL_DIAG_TILES, sy, info);
         if (role == SERVICE_D0) SERVICE_STAMP(p, 4);
         panel_next_diag_role(sm, pan, ld, packed + panel_offset(n_pad, p + 1), panel_ld(n_pad, p + 1), info, sy, role - SERVICE_D0, tid,
                              (role == SERVICE_D0 && trace) ? trace + 16 * p + 5 : nullptr);
@@ -1216,8 +1219,9 @@ __global__ __launch_bounds__(256, 2) void panel_strips_kernel(double* packed, in
 //   the rest                                all other tiles (XCD-contiguous ranges), the diagonal block of panel p + 2 first (-> ready_d2)
 // A strip workgroup can only be running when every ticket before it has started, so the tiles it waits for are running or done,
 // and those wait only on the service: no deadlock whatever the dispatch order.
+// q_end: the targets are the panels (p, q_end) -- the rest of the group.
 __global__ __launch_bounds__(256, 2) void trailing_service_kernel(double* packed, int64_t n_pad, int p, int ntiles, int nstrips, PanelSync* sy_base,
-                                                                  int* ready, int* rowcnt, double* winv, int* info, unsigned long long* trace) {
+                                                                  int* ready, int* rowcnt, double* winv, int* info, unsigned long long* trace, int q_end) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ int sh_ticket;
   const int P = (int)(n_pad / NB);
@@ -1261,7 +1265,7 @@ __global__ __launch_bounds__(256, 2) void trailing_service_kernel(double* packed
       id -= T1;
       s = 2;
       for (;; ++s) {
-        if (p + 1 + s >= P) return;
+        if (p + 1 + s >= q_end) return;
         const int tq = TPP * TPP * (P - p - 1 - s) - TPP * (TPP - 1) / 2;
         if (id < tq) break;
         id -= tq;
@@ -1358,7 +1362,8 @@ int launch_inv512(hipStream_t s, const double* packed, int64_t n_pad, const doub
   return 0;
 }
 
-int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync, void* trace, double* inv) {
+int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync, void* trace, double* inv,
+                         int64_t p_begin, int64_t p_end) {
   static bool attr_set[MAX_DEVICES] = {};
   const size_t smem = PB_SMEM_DOUBLES * sizeof(double);
   int dev = 0;
@@ -1372,15 +1377,16 @@ int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* w
   int* ready = reinterpret_cast<int*>(static_cast<char*>(sync) + (size_t)P * sizeof(PanelSync));
   ProfScope ps(s, PK_PANEL_FUSED, 0.0, 0.0);
   hipLaunchKernelGGL(panel_service_kernel, dim3(SERVICE_WGS), dim3(512), smem, s, packed, n_pad, winv, info_dev, sy, ready, (int)P,
-                     static_cast<unsigned long long*>(trace), inv);
+                     static_cast<unsigned long long*>(trace), inv, (int)p_begin, (int)p_end);
   GPRC_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_service_gate(hipStream_t s, int64_t n_pad, int* info_dev, void* sync) {
+// launches: service launches so far on this sync buffer, this one included (the "resident" counter is cumulative)
+int launch_service_gate(hipStream_t s, int64_t n_pad, int* info_dev, void* sync, int launches) {
   const int64_t P = n_pad / NB;
   int* ready = reinterpret_cast<int*>(static_cast<char*>(sync) + (size_t)P * sizeof(PanelSync));
-  hipLaunchKernelGGL(service_gate_kernel, dim3(1), dim3(64), 0, s, ready + 3 * P, SERVICE_WGS, info_dev);
+  hipLaunchKernelGGL(service_gate_kernel, dim3(1), dim3(64), 0, s, ready + 3 * P, SERVICE_WGS * launches, info_dev);
   GPRC_LAUNCH_CHECK();
   return 0;
 }
@@ -1399,15 +1405,16 @@ int launch_panel_strips(hipStream_t s, double* packed, int64_t n_pad, int64_t p,
   return 0;
 }
 
-// the caller's-stream kernel of panel p under the service: the trailing update of panel p (everything behind p except the next
-// diagonal block) + the ordinary strips of panel p + 1
-int launch_trailing_service(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync, void* trace) {
+// the caller's-stream kernel of panel p under the service: the trailing update of panel p over the targets (p, q_end) (everything
+// except the next diagonal block) + the ordinary strips of panel p + 1
+int launch_trailing_service(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync, void* trace, int64_t q_end) {
   const int64_t P = n_pad / NB;
-  if (P - p - 1 < 2) return 0;   // one panel left: its diagonal block is all there is, and the service owns it
+  if (q_end > P) q_end = P;
+  if (q_end - p - 1 < 1 || p + 2 >= P) return 0;   // no target, or the only target is the last panel: its diagonal block is all there is
   GPRC_TRY(ensure_gemm_attrs());
   int64_t tiles = -(int64_t)PANEL_DIAG_TILES;
   double fl = 0.0, by = 0.0;
-  for (int64_t q = p + 1; q < P; ++q) {
+  for (int64_t q = p + 1; q < q_end; ++q) {
     tiles += (int64_t)TPP * TPP * (P - q) - TPP * (TPP - 1) / 2;
     const double rows = (double)(n_pad - q * NB);
     const double elems = rows * NB - 0.5 * NB * (double)(NB - 1) - (q == p + 1 ? 0.5 * NB * (double)(NB + 1) : 0.0);
@@ -1424,7 +1431,7 @@ int launch_trailing_service(hipStream_t s, double* packed, int64_t n_pad, int64_
   const int64_t n_first = (int64_t)TPP * TPP * (P - p - 1) - TPP * (TPP - 1) / 2 - PANEL_DIAG_TILES;
   const int64_t base = (n_first + nstrips + 7) & ~(int64_t)7;     // ticketed workgroups, padded to a multiple of the XCD count
   hipLaunchKernelGGL(trailing_service_kernel, dim3((unsigned)(base + (tiles - n_first))), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)p,
-                     (int)tiles, (int)nstrips, sy, ready, rowcnt, winv, info_dev, static_cast<unsigned long long*>(trace));
+                     (int)tiles, (int)nstrips, sy, ready, rowcnt, winv, info_dev, static_cast<unsigned long long*>(trace), (int)q_end);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

@@ -83,6 +83,37 @@ def test_sweep_variants_are_bit_identical():
     ctx.close()
 
 
+def test_grouped_left_looking_with_the_service_inside_the_groups(monkeypatch):
+    """The whole-sweep call takes the panels in groups: a left-looking pass brings a group's columns up to date, inside the group
+    the factor service runs (its launch restricted to the group: the block behind the group is left to that block's own pass).
+    Any grouping gives the bits of the launch-per-panel sweep; n = 9100: 18 panels, groups of 1, 2-3, ~6 and all."""
+    n = 9100
+    L, ctx, g, K = _filled(n, seed=6)
+    P = g.P
+    a = K.clone(); w, info = _new(g)
+    for p in range(P):
+        nat.check(L.gprc_dev_factor_panel(ctx.handle, a.data_ptr(), g.n_pad, p, w.data_ptr(), info.data_ptr()))
+        if p + 1 < P:
+            nat.check(L.gprc_dev_update_trailing(ctx.handle, a.data_ptr(), g.n_pad, p, p + 1, P, 1))
+    torch.cuda.synchronize()
+    assert int(info[0]) == 0
+    inv_ref = None
+    for want in ("1", "500", "1500", "right"):
+        monkeypatch.setenv("GPRC_FACTOR", want)
+        b = K.clone(); w2, info2 = _new(g); inv2 = _new_inv(g)
+        nat.check(L.gprc_dev_factor_all(ctx.handle, b.data_ptr(), g.n_pad, w2.data_ptr(), info2.data_ptr(), inv2.data_ptr()))
+        torch.cuda.synchronize()
+        assert int(info2[0]) == 0, want
+        assert torch.equal(b, a) and torch.equal(w2, w), want
+        blk = torch.arange(512, device="cuda") // 128
+        written = (blk[None, :] <= blk[:, None])
+        T = inv2.view(P, 512, 512)[:, written]
+        if inv_ref is None:
+            inv_ref = T
+        assert torch.equal(T, inv_ref), want
+    ctx.close()
+
+
 @pytest.mark.parametrize("n", [600, 1100, 1536, 9100])
 def test_factor_service_is_bit_identical_to_the_launch_per_panel_sweep(n):
     """gprc_dev_factor_all at these sizes is the factor service (one persistent launch carrying every panel's dependent chain,
