@@ -58,8 +58,10 @@ struct TrsvGate { int done; int near; };   // one per panel, zeroed before the s
                                            // workgroups of the previous panel's launch that have finished (whole-solve form only)
 constexpr int TRSV_DIAG_WGS = 16;
 constexpr int TRSV_DIAG_ROWS = NB / TRSV_DIAG_WGS;   // 32
-constexpr int TRSV_NEAR_FWD = NB / 128;              // workgroups of a forward launch that cover the next panel's 512 rows
-constexpr int TRSV_NEAR_BWD = NB / 64;               // workgroups of a backward launch that cover the previous panel's 512 columns
+constexpr int TRSV_ROWS = 32;                        // rows per forward product workgroup (x 4 column groups x 4 fma chains = 512 threads)
+constexpr int TRSV_COLS = 16;                        // columns per backward product workgroup (8 waves x 2 columns)
+constexpr int TRSV_NEAR_FWD = NB / TRSV_ROWS;        // workgroups of a forward launch that cover the next panel's 512 rows
+constexpr int TRSV_NEAR_BWD = NB / TRSV_COLS;        // workgroups of a backward launch that cover the previous panel's 512 columns
 
 // the whole workgroup calls it; returns false on a timeout
 __device__ __forceinline__ bool trsv_count_wait(int* ctr, int need, int* sh) {
@@ -86,18 +88,13 @@ __device__ __forceinline__ void trsv_count_arrive(int* ctr) {   // the whole wor
   }
 }
 
-// One row's share of L[row, panel p columns] * x_p for column group g (NB/4 columns): four interleaved fma chains,
-// combined (s0 + s1) + (s2 + s3).
-__device__ __forceinline__ double gemv_group_partial(const double* Lr, int64_t ld, const double* xg) {
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll 4
-  for (int c = 0; c < NB / 4; c += 4) {
-    s0 = fma(Lr[(int64_t)c * ld], xg[c], s0);
-    s1 = fma(Lr[(int64_t)(c + 1) * ld], xg[c + 1], s1);
-    s2 = fma(Lr[(int64_t)(c + 2) * ld], xg[c + 2], s2);
-    s3 = fma(Lr[(int64_t)(c + 3) * ld], xg[c + 3], s3);
-  }
-  return (s0 + s1) + (s2 + s3);
+// One row's share of L[row, panel p columns] * x_p for column group g (NB/4 columns) is four interleaved fma chains (chain k: columns
+// k, k + 4, ...), combined (s0 + s1) + (s2 + s3).  One thread runs ONE chain; the four chains of a (row, group) sit in adjacent lanes.
+__device__ __forceinline__ double gemv_chain(const double* Lr, int64_t ld, const double* xg, int k) {
+  double s = 0.0;
+#pragma unroll 8
+  for (int c = k; c < NB / 4; c += 4) s = fma(Lr[(int64_t)c * ld], xg[c], s);
+  return s;
 }
 
 // One column's dot product with x_p over the NB rows of panel p (lanes stride the rows, fixed fma chain + wave tree)
@@ -145,47 +142,87 @@ __device__ __forceinline__ void trsv_fwd_diag(const double* inv, int p, double* 
   }
 }
 
-// 128 rows starting at `row0` (global row index) x the NB columns of panel p, 4 column groups: b[row] -= L[row, panel p] x_p
+// TRSV_ROWS rows starting at `row0` (global row index) x the NB columns of panel p: b[row] -= L[row, panel p] x_p.  Thread =
+// (chain k = t & 3, row i = (t >> 2) & 31, column group g = t >> 7): a row's 16 chain sums are combined per group as (s0 + s1) +
+// (s2 + s3) with two lane exchanges, the four groups as (r0 + r1) + (r2 + r3) through LDS -- the summation tree of a row is fixed.
+// (32 rows per workgroup instead of 128: the 2 MB block next to the diagonal, and at small n the whole product, is spread over four
+// times as many CUs -- a CU streams ~100 GB/s.)
 __device__ __forceinline__ void trsv_fwd_rows(const double* packed, int64_t n_pad, int p, double* b, const double* zbuf, int64_t row0, bool ok,
-                                              double* xs, double (*red)[128]) {
-  const int t = threadIdx.x, i = t & 127, g = t >> 7;
+                                              double* xs, double (*red)[TRSV_ROWS]) {
+  const int t = threadIdx.x, k = t & 3, i = (t >> 2) & (TRSV_ROWS - 1), g = t >> 7;
   const int64_t ld = panel_ld(n_pad, p);
   const int64_t row = row0 + i;
   const double* Lr = packed + panel_offset(n_pad, p) + (row - (int64_t)p * NB) + (int64_t)(g * (NB / 4)) * ld;
   for (int c = t; c < NB; c += 512) xs[c] = zbuf[(int64_t)p * NB + c];
   __syncthreads();
-  red[g][i] = gemv_group_partial(Lr, ld, xs + g * (NB / 4));
+  double s = gemv_chain(Lr, ld, xs + g * (NB / 4), k);
+  s += __shfl_xor(s, 1, 64);                      // lanes k = 0, 1: s0 + s1; lanes 2, 3: s2 + s3 (addition commutes bitwise)
+  s += __shfl_xor(s, 2, 64);                      // (s0 + s1) + (s2 + s3)
+  if (k == 0) red[g][i] = s;
+  __syncthreads();
+  if (t < TRSV_ROWS) {
+    const int64_t r = row0 + t;
+    b[r] = ok ? b[r] - ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) : __builtin_nan("");
+  }
+}
+
+// The same product for 128 rows per workgroup (thread = row x column group, the four chains of a group in one thread): 1 KB
+// contiguous per column instead of 256 B -- the better HBM access pattern, used for the rows far from the diagonal of large factors
+// (n = 65536: 4.6 against 5.1 ms per forward solve); the summation tree of a row is the same, so are the bits.
+__device__ __forceinline__ void trsv_fwd_rows128(const double* packed, int64_t n_pad, int p, double* b, const double* zbuf, int64_t row0, bool ok,
+                                                 double* xs, double (*red)[128]) {
+  const int t = threadIdx.x, i = t & 127, g = t >> 7;
+  const int64_t ld = panel_ld(n_pad, p);
+  const int64_t row = row0 + i;
+  const double* Lr = packed + panel_offset(n_pad, p) + (row - (int64_t)p * NB) + (int64_t)(g * (NB / 4)) * ld;
+  const double* xg = xs + g * (NB / 4);
+  for (int c = t; c < NB; c += 512) xs[c] = zbuf[(int64_t)p * NB + c];
+  __syncthreads();
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+  for (int c = 0; c < NB / 4; c += 4) {
+    s0 = fma(Lr[(int64_t)c * ld], xg[c], s0);
+    s1 = fma(Lr[(int64_t)(c + 1) * ld], xg[c + 1], s1);
+    s2 = fma(Lr[(int64_t)(c + 2) * ld], xg[c + 2], s2);
+    s3 = fma(Lr[(int64_t)(c + 3) * ld], xg[c + 3], s3);
+  }
+  red[g][i] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (g == 0) b[row] = ok ? b[row] - ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) : __builtin_nan("");
 }
 
-// Forward launch of panel p.
-// FUSED = false (gprc_dev_trsv_step): blocks [0, 16) the diagonal step of panel p; blocks >= 16: 128 rows below the panel each, after
+// Forward launch of panel p.  far128 != 0: the rows behind the next panel's are taken 128 per workgroup (large factors).
+// FUSED = false (gprc_dev_trsv_step): blocks [0, 16) the diagonal step of panel p; blocks >= 16: 32 rows below the panel each, after
 //   the gate.
-// FUSED = true (inside a whole solve; x_p is already in zbuf -- the previous launch left it): blocks [0, 4) the rows of panel p + 1,
-//   counting into that panel's `near`; blocks [4, 20) the DIAGONAL STEP OF PANEL p + 1, which so runs while the other blocks
-//   (>= 20: the rows behind panel p + 1) are still streaming; nobody waits for anything but those four.
+// FUSED = true (inside a whole solve; x_p is already in zbuf -- the previous launch left it): blocks [0, 16) the rows of panel p + 1,
+//   counting into that panel's `near`; blocks [16, 32) the DIAGONAL STEP OF PANEL p + 1, which so runs while the other blocks
+//   (>= 32: the rows behind panel p + 1) are still streaming; nobody waits for anything but those sixteen.
 template <bool FUSED>
 __global__ __launch_bounds__(512) void trsv_fwd_kernel(const double* packed, const double* inv, int64_t n_pad, int p, double* b, double* zbuf,
-                                                       TrsvGate* gates) {
+                                                       TrsvGate* gates, int far128) {
   __shared__ double xs[NB];
-  __shared__ double red[4][128];
+  __shared__ double red[4][TRSV_ROWS];
+  __shared__ double red128[4][128];
   __shared__ int sh_ok;
   const int bid = (int)blockIdx.x;
   if constexpr (!FUSED) {
     if (bid < TRSV_DIAG_WGS) { trsv_fwd_diag(inv, p, b, zbuf, gates + p, bid, xs, &sh_ok); return; }
     const bool ok = trsv_count_wait(&gates[p].done, TRSV_DIAG_WGS, &sh_ok);
-    trsv_fwd_rows(packed, n_pad, p, b, zbuf, (int64_t)(p + 1) * NB + (int64_t)(bid - TRSV_DIAG_WGS) * 128, ok, xs, red);
+    const int rb = bid - TRSV_DIAG_WGS;                  // the next panel's rows always 32 per workgroup, the rest 32 or 128
+    if (rb < TRSV_NEAR_FWD || !far128) trsv_fwd_rows(packed, n_pad, p, b, zbuf, (int64_t)(p + 1) * NB + (int64_t)rb * TRSV_ROWS, ok, xs, red);
+    else trsv_fwd_rows128(packed, n_pad, p, b, zbuf, (int64_t)(p + 2) * NB + (int64_t)(rb - TRSV_NEAR_FWD) * 128, ok, xs, red128);
   } else {
     if (bid < TRSV_NEAR_FWD) {
-      trsv_fwd_rows(packed, n_pad, p, b, zbuf, (int64_t)(p + 1) * NB + (int64_t)bid * 128, true, xs, red);
+      trsv_fwd_rows(packed, n_pad, p, b, zbuf, (int64_t)(p + 1) * NB + (int64_t)bid * TRSV_ROWS, true, xs, red);
       trsv_count_arrive(&gates[p + 1].near);
     } else if (bid < TRSV_NEAR_FWD + TRSV_DIAG_WGS) {
       const bool ok = trsv_count_wait(&gates[p + 1].near, TRSV_NEAR_FWD, &sh_ok);
       trsv_fwd_diag(inv, p + 1, b, zbuf, gates + p + 1, bid - TRSV_NEAR_FWD, xs, &sh_ok);
       if (!ok && threadIdx.x < TRSV_DIAG_ROWS) b[(int64_t)(p + 1) * NB + TRSV_DIAG_ROWS * (bid - TRSV_NEAR_FWD) + threadIdx.x] = __builtin_nan("");
     } else {
-      trsv_fwd_rows(packed, n_pad, p, b, zbuf, (int64_t)(p + 2) * NB + (int64_t)(bid - TRSV_NEAR_FWD - TRSV_DIAG_WGS) * 128, true, xs, red);
+      const int rb = bid - TRSV_NEAR_FWD - TRSV_DIAG_WGS;
+      if (!far128) trsv_fwd_rows(packed, n_pad, p, b, zbuf, (int64_t)(p + 2) * NB + (int64_t)rb * TRSV_ROWS, true, xs, red);
+      else trsv_fwd_rows128(packed, n_pad, p, b, zbuf, (int64_t)(p + 2) * NB + (int64_t)rb * 128, true, xs, red128);
     }
   }
 }
@@ -228,23 +265,24 @@ __device__ __forceinline__ void trsv_bwd_diag(const double* inv, int p, double* 
   if (g == 0) xp[c] = ok ? v : __builtin_nan("");
 }
 
-// 64 columns (cg) of the earlier panel q: x[q NB + c] -= L[panel-p rows, that column]^T x_p; one wave per column at a time
+// TRSV_COLS columns (group cg) of the earlier panel q: x[q NB + c] -= L[panel-p rows, that column]^T x_p; a wave per column, two
+// columns per wave
 __device__ __forceinline__ void trsv_bwd_cols(const double* packed, int64_t n_pad, int p, double* x, const double* zbuf, int q, int cg, bool ok, double* xs) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int64_t ldq = panel_ld(n_pad, q);
   const double* blk = packed + panel_offset(n_pad, q) + (int64_t)(p - q) * NB;  // rows of panel p inside panel q
   for (int r = t; r < NB; r += 512) xs[r] = zbuf[(int64_t)p * NB + r];
   __syncthreads();
-#pragma unroll 2
-  for (int k = 0; k < 8; ++k) {
-    const int c = cg * 64 + w * 8 + k;
+#pragma unroll
+  for (int k = 0; k < TRSV_COLS / 8; ++k) {
+    const int c = cg * TRSV_COLS + w * (TRSV_COLS / 8) + k;
     const double s = gemvt_column_dot(blk + (int64_t)c * ldq, xs, lane);
     if (lane == 0) x[(int64_t)q * NB + c] = ok ? x[(int64_t)q * NB + c] - s : __builtin_nan("");
   }
 }
 
-// Backward launch of panel p; FUSED as above with "previous panel" = p - 1: blocks [0, 8) its 512 columns (-> near), blocks [8, 24)
-// its diagonal step, blocks >= 24 the panels q < p - 1.
+// Backward launch of panel p; FUSED as above with "previous panel" = p - 1: blocks [0, 32) its 512 columns (-> near), blocks [32, 48)
+// its diagonal step, blocks >= 48 the panels q < p - 1.
 template <bool FUSED>
 __global__ __launch_bounds__(512) void trsv_bwd_kernel(const double* packed, const double* inv, int64_t n_pad, int p, double* x, double* zbuf,
                                                        TrsvGate* gates) {
@@ -256,7 +294,7 @@ __global__ __launch_bounds__(512) void trsv_bwd_kernel(const double* packed, con
     if (bid < TRSV_DIAG_WGS) { trsv_bwd_diag(inv, p, x, zbuf, gates + p, bid, xs, red, &sh_ok); return; }
     const int cb = bid - TRSV_DIAG_WGS;
     const bool ok = trsv_count_wait(&gates[p].done, TRSV_DIAG_WGS, &sh_ok);
-    trsv_bwd_cols(packed, n_pad, p, x, zbuf, cb / (NB / 64), cb % (NB / 64), ok, xs);
+    trsv_bwd_cols(packed, n_pad, p, x, zbuf, cb / (NB / TRSV_COLS), cb % (NB / TRSV_COLS), ok, xs);
   } else {
     if (bid < TRSV_NEAR_BWD) {
       trsv_bwd_cols(packed, n_pad, p, x, zbuf, p - 1, bid, true, xs);
@@ -267,7 +305,7 @@ __global__ __launch_bounds__(512) void trsv_bwd_kernel(const double* packed, con
       if (!ok && threadIdx.x < TRSV_DIAG_ROWS) x[(int64_t)(p - 1) * NB + TRSV_DIAG_ROWS * (bid - TRSV_NEAR_BWD) + threadIdx.x] = __builtin_nan("");
     } else {
       const int cb = bid - TRSV_NEAR_BWD - TRSV_DIAG_WGS;
-      trsv_bwd_cols(packed, n_pad, p, x, zbuf, cb / (NB / 64), cb % (NB / 64), true, xs);
+      trsv_bwd_cols(packed, n_pad, p, x, zbuf, cb / (NB / TRSV_COLS), cb % (NB / TRSV_COLS), true, xs);
     }
   }
 }
@@ -469,6 +507,15 @@ int64_t rowreduce_splits(int64_t cols) { return (cols + RR_COLS - 1) / RR_COLS; 
 // work (gprc_trsv_work_size(n_pad) doubles): x_p staging (n_pad doubles) and one gate per panel behind it
 static inline TrsvGate* trsv_gates(double* work, int64_t n_pad) { return reinterpret_cast<TrsvGate*>(work + n_pad); }
 
+// rows behind the next panel's in 128-row workgroups from this size on (the HBM access pattern outweighs the parallelism)
+static inline int trsv_far128(int64_t n_pad) { return n_pad >= 32768 ? 1 : 0; }
+// workgroups of a forward launch for `rows` rows below the panel (first the next panel's NB rows, 32 per workgroup)
+static inline unsigned trsv_fwd_row_wgs(int64_t rows, int far128) {
+  if (rows <= 0) return 0;
+  const int64_t far = rows - NB;
+  return (unsigned)(TRSV_NEAR_FWD + (far > 0 ? far / (far128 ? 128 : TRSV_ROWS) : 0));
+}
+
 // one panel step of the solve: x_p, then its contribution to the rest of the right-hand side (one launch)
 int launch_trsv_step(hipStream_t s, const double* packed, const double* inv, int64_t n_pad, double* b, int transpose, int p, double* work) {
   const int P = (int)(n_pad / NB);
@@ -476,11 +523,12 @@ int launch_trsv_step(hipStream_t s, const double* packed, const double* inv, int
   if (!inv || !work) { set_error("trsv_step: the explicit diagonal inverses and the work buffer are required"); return GPRC_ERR_ARG; }
   TrsvGate* gates = trsv_gates(work, n_pad);
   GPRC_HIP(hipMemsetAsync(gates + p, 0, sizeof(TrsvGate), s));
+  const int f128 = trsv_far128(n_pad);
   if (!transpose) {
     const int64_t below = n_pad - (int64_t)(p + 1) * NB;
-    hipLaunchKernelGGL(trsv_fwd_kernel<false>, dim3((unsigned)(TRSV_DIAG_WGS + below / 128)), dim3(512), 0, s, packed, inv, n_pad, p, b, work, gates);
+    hipLaunchKernelGGL(trsv_fwd_kernel<false>, dim3(TRSV_DIAG_WGS + trsv_fwd_row_wgs(below, f128)), dim3(512), 0, s, packed, inv, n_pad, p, b, work, gates, f128);
   } else {
-    hipLaunchKernelGGL(trsv_bwd_kernel<false>, dim3((unsigned)(TRSV_DIAG_WGS + p * (NB / 64))), dim3(512), 0, s, packed, inv, n_pad, p, b, work, gates);
+    hipLaunchKernelGGL(trsv_bwd_kernel<false>, dim3((unsigned)(TRSV_DIAG_WGS + p * (NB / TRSV_COLS))), dim3(512), 0, s, packed, inv, n_pad, p, b, work, gates);
   }
   GPRC_LAUNCH_CHECK();
   return 0;
@@ -497,28 +545,29 @@ int launch_trsv(hipStream_t s, const double* packed, const double* inv, int64_t 
   TrsvGate* gates = trsv_gates(work, n_pad);
   GPRC_HIP(hipMemsetAsync(gates, 0, sizeof(TrsvGate) * (size_t)P, s));
   static const bool steps = [] { const char* e = std::getenv("GPRC_TRSV"); return e && std::strcmp(e, "steps") == 0; }();
+  const int f128 = trsv_far128(n_pad);
   if (!transpose) {
     if (steps) {
       for (int p = 0; p < P; ++p) {
         const int64_t below = n_pad - (int64_t)(p + 1) * NB;
-        hipLaunchKernelGGL(trsv_fwd_kernel<false>, dim3((unsigned)(TRSV_DIAG_WGS + below / 128)), dim3(512), 0, s, packed, inv, n_pad, p, b, work, gates);
+        hipLaunchKernelGGL(trsv_fwd_kernel<false>, dim3(TRSV_DIAG_WGS + trsv_fwd_row_wgs(below, f128)), dim3(512), 0, s, packed, inv, n_pad, p, b, work, gates, f128);
       }
     } else {
-      hipLaunchKernelGGL(trsv_fwd_kernel<false>, dim3(TRSV_DIAG_WGS), dim3(512), 0, s, packed, inv, n_pad, 0, b, work, gates);
+      hipLaunchKernelGGL(trsv_fwd_kernel<false>, dim3(TRSV_DIAG_WGS), dim3(512), 0, s, packed, inv, n_pad, 0, b, work, gates, f128);
       for (int p = 0; p + 1 < P; ++p) {
         const int64_t behind = n_pad - (int64_t)(p + 2) * NB;
-        hipLaunchKernelGGL(trsv_fwd_kernel<true>, dim3((unsigned)(TRSV_NEAR_FWD + TRSV_DIAG_WGS + behind / 128)), dim3(512), 0, s, packed, inv, n_pad, p, b,
-                           work, gates);
+        hipLaunchKernelGGL(trsv_fwd_kernel<true>, dim3((unsigned)(TRSV_NEAR_FWD + TRSV_DIAG_WGS + behind / (f128 ? 128 : TRSV_ROWS))), dim3(512), 0, s, packed, inv,
+                           n_pad, p, b, work, gates, f128);
       }
     }
   } else {
     if (steps) {
       for (int p = P - 1; p >= 0; --p)
-        hipLaunchKernelGGL(trsv_bwd_kernel<false>, dim3((unsigned)(TRSV_DIAG_WGS + p * (NB / 64))), dim3(512), 0, s, packed, inv, n_pad, p, b, work, gates);
+        hipLaunchKernelGGL(trsv_bwd_kernel<false>, dim3((unsigned)(TRSV_DIAG_WGS + p * (NB / TRSV_COLS))), dim3(512), 0, s, packed, inv, n_pad, p, b, work, gates);
     } else {
       hipLaunchKernelGGL(trsv_bwd_kernel<false>, dim3(TRSV_DIAG_WGS), dim3(512), 0, s, packed, inv, n_pad, P - 1, b, work, gates);
       for (int p = P - 1; p >= 1; --p)
-        hipLaunchKernelGGL(trsv_bwd_kernel<true>, dim3((unsigned)(TRSV_NEAR_BWD + TRSV_DIAG_WGS + (p - 1) * (NB / 64))), dim3(512), 0, s, packed, inv, n_pad, p,
+        hipLaunchKernelGGL(trsv_bwd_kernel<true>, dim3((unsigned)(TRSV_NEAR_BWD + TRSV_DIAG_WGS + (p - 1) * (NB / TRSV_COLS))), dim3(512), 0, s, packed, inv, n_pad, p,
                            b, work, gates);
     }
   }

@@ -192,6 +192,33 @@ def test_solve_in_panel_steps_is_bit_identical(n, reps):
     ctx.close()
 
 
+def test_solve_in_panel_steps_is_bit_identical_at_a_large_size():
+    """From n_pad = 32768 on, the forward product takes the rows far from the diagonal 128 per workgroup (the better HBM access
+    pattern) instead of 32: another thread layout of the same summation tree.  Whole solve against per-panel steps at n = 33000
+    (65 panels): every word equal, both directions; and L^T (L x) reproduces the right-hand side's solve (residual through the
+    packed factor itself: x from the solves, then forward-substituted back by the per-step launches of the OTHER direction)."""
+    n = 33000
+    L, ctx, g, a = _filled(n, seed=33)
+    w, info = _new(g)
+    inv = _new_inv(g)
+    nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr(), inv.data_ptr()))
+    torch.cuda.synchronize()
+    assert int(info[0]) == 0
+    b0 = torch.from_numpy(np.concatenate([np.random.default_rng(2).normal(size=n), np.zeros(g.n_pad - n)])).cuda()
+    work = torch.zeros(g.trsv_work, dtype=torch.float64, device="cuda")
+    work2 = torch.zeros(g.trsv_work, dtype=torch.float64, device="cuda")
+    for transpose in (0, 1):
+        steps = b0.clone()
+        for p in (range(g.P) if not transpose else range(g.P - 1, -1, -1)):
+            nat.check(L.gprc_dev_trsv_step(ctx.handle, a.data_ptr(), inv.data_ptr(), g.n_pad, steps.data_ptr(), transpose, p, work2.data_ptr()))
+        whole = b0.clone()
+        nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), inv.data_ptr(), g.n_pad, whole.data_ptr(), transpose, work.data_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(whole, steps), transpose
+        assert bool(torch.isfinite(whole).all())
+    ctx.close()
+
+
 def test_k_chunked_left_looking_passes_are_bit_identical():
     """GPRC_KCHUNK cuts the long-K left-looking passes (predict solve and Cholesky trailing update) into several launches
     over K ranges; same products in the same order, so the factor and the prediction must not change by a bit.  The
