@@ -85,6 +85,7 @@ PROTOTYPES = {
     "gprc_dev_factor_panel": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "gprc_dev_factor_subpanel": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _vp]),
     "gprc_dev_factor_all": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "gprc_factor_service": (C.c_int, [C.c_int]),
     "gprc_solve_inv_size": (_i64, [_i64]),
     "gprc_dev_solve_prepare": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i64]),
     "gprc_dev_update_trailing": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64]),
@@ -190,6 +191,7 @@ def device_count() -> int:
     return c.value
 
 
+INFO_WAIT_TIMEOUT = -99   # include/gprc_native.h: a device-side dependency wait ran out
 PROF_KINDS = ["fill", "potf2_inv", "trsm_panel", "gemm_inner_k128", "trailing_update", "solve_update_k512", "trsv",
               "row_reduce", "cov_syrk", "deriv_rowsum", "jacobi_sweep", "solve_left", "trailing_left", "panel_fused", "solve_panel"]
 

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -395,6 +396,11 @@ int factor_all_lookahead(gprc_ctx* ctx, double* packed, int64_t n_pad, double* w
   return 0;
 }
 
+// Set when a factorisation under the factor service ended in a device-side wait timeout: the persistent launch and the caller's
+// kernels did not run concurrently (a tool that serialises dispatches, e.g. rocprofv3 --pmc).  From then on this process factors with
+// one fused launch per panel (what GPRC_SERVICE=0 selects).
+static std::atomic<bool> g_service_off{false};
+
 // Lower tiles a group of the left-looking schedule should have at least (see factor_all_async)
 static int64_t want_for(int64_t n_pad) {
   // below n_pad = 20480 one group -- the plain right-looking sweep under the factor service -- is fastest (measured,
@@ -440,7 +446,7 @@ int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv,
     GPRC_TRY(factor_all_lookahead(ctx, packed, n_pad, winv, info_dev));
     return inv ? launch_inv512(s, packed, n_pad, winv, inv, 0, P) : 0;
   }
-  const bool service = !panel_steps && sv_env != 0 && P >= 2;
+  const bool service = !panel_steps && sv_env != 0 && P >= 2 && !g_service_off.load();
   DevMem sync;   // flags of every panel + the counters; goes back to the pool when every launch below has been ordered behind it
   void* trace = nullptr;
   if (service) {
@@ -476,13 +482,32 @@ int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv,
   return (inv && !service) ? launch_inv512(s, packed, n_pad, winv, inv, 0, P) : 0;
 }
 
-int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_host, double* inv = nullptr) {
+int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_host, double* inv = nullptr);
+
+// factor_all for callers that can rebuild the matrix: if the factor service timed out (see g_service_off), once per process the
+// matrix is rebuilt (refill) and factored again without the service instead of failing the call.
+template <class Refill>
+int factor_all_or_refill(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_host, double* inv, Refill refill) {
+  int rc = factor_all(ctx, packed, n_pad, winv, info_host, inv);
+  if (rc == GPRC_ERR_HIP && *info_host == GPRC_INFO_WAIT_TIMEOUT && !g_service_off.exchange(true)) {
+    GPRC_TRY(refill());
+    rc = factor_all(ctx, packed, n_pad, winv, info_host, inv);
+  }
+  return rc;
+}
+
+int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_host, double* inv) {
   hipStream_t s = ctx->stream;
   GPRC_HIP(hipMemsetAsync(ctx->info_dev, 0, sizeof(int), s));
   GPRC_TRY(factor_all_async(ctx, packed, n_pad, winv, ctx->info_dev, inv));
   GPRC_HIP(hipMemcpyAsync(info_host, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
   GPRC_HIP(hipStreamSynchronize(s));
-  if (*info_host < 0) { set_error("fused panel kernel: a device-side dependency wait timed out (info = " + std::to_string(*info_host) + "); the factor is not valid"); return GPRC_ERR_HIP; }
+  if (*info_host < 0) {
+    set_error("factorisation: a device-side dependency wait timed out (info = " + std::to_string(*info_host) +
+              "); the factor is not valid.  The factor service needs its persistent launch and the caller's kernels to run CONCURRENTLY: "
+              "under a tool that serialises dispatches (e.g. rocprofv3 --pmc) set GPRC_SERVICE=0");
+    return GPRC_ERR_HIP;
+  }
   return 0;
 }
 
@@ -575,12 +600,16 @@ int gpr_attempt(gprc_model* m, double noise, int* info_out) {
   gprc_ctx* ctx = m->ctx;
   hipStream_t s = ctx->stream;
   const int64_t n = m->n, n_pad = m->n_pad, P = n_pad / NB;
-  for (int64_t p = 0; p < P; ++p)
-    GPRC_TRY(launch_fill(s, m->ks, m->X, n, m->X, n, m->d, m->packed + panel_offset(n_pad, p), panel_ld(n_pad, p), p * NB,
-                         n_pad - p * NB, p * NB, NB, PAD_IDENTITY, noise));
+  auto fill = [&]() -> int {
+    for (int64_t p = 0; p < P; ++p)
+      GPRC_TRY(launch_fill(s, m->ks, m->X, n, m->X, n, m->d, m->packed + panel_offset(n_pad, p), panel_ld(n_pad, p), p * NB,
+                           n_pad - p * NB, p * NB, NB, PAD_IDENTITY, noise));
+    return 0;
+  };
+  GPRC_TRY(fill());
   DevMem inv;   // explicit inverses of the diagonal blocks: needed by the two vector solves only
   GPRC_TRY(inv.alloc(gprc_solve_inv_size(n_pad)));
-  GPRC_TRY(factor_all(ctx, m->packed, n_pad, m->winv, info_out, inv.p));
+  GPRC_TRY(factor_all_or_refill(ctx, m->packed, n_pad, m->winv, info_out, inv.p, fill));
   if (*info_out != 0) return 0;
   GPRC_HIP(hipMemcpyAsync(m->alpha, m->y, sizeof(double) * n_pad, hipMemcpyDeviceToDevice, s));
   GPRC_TRY(launch_trsv(s, m->packed, inv.p, n_pad, m->alpha, 0, m->work));
@@ -655,9 +684,10 @@ int mvn_factor_dev(gprc_ctx* ctx, const double* cov_dev, int64_t ld, int64_t m, 
     DevMem packed, winv;
     GPRC_TRY(packed.alloc(gprc_packed_size(n_pad)));
     GPRC_TRY(winv.alloc(gprc_winv_size(n_pad)));
-    GPRC_TRY(launch_pack_dense(s, cov_dev, ld, m, n_pad, packed.p));
+    auto pack = [&]() -> int { return launch_pack_dense(s, cov_dev, ld, m, n_pad, packed.p); };
+    GPRC_TRY(pack());
     int info = 0;
-    GPRC_TRY(factor_all(ctx, packed.p, n_pad, winv.p, &info));
+    GPRC_TRY(factor_all_or_refill(ctx, packed.p, n_pad, winv.p, &info, nullptr, pack));
     if (info == 0) {
       GPRC_TRY(launch_unpack_L(s, packed.p, n_pad, m, L_dev, m));
       GPRC_HIP(hipStreamSynchronize(s));
@@ -1111,9 +1141,10 @@ int gprc_gpc_fit(gprc_ctx* ctx, int kernel, const double* params, int n_params, 
   for (;;) {
     ++it;
     GPC_TRY(launch_gpc_pre(s, f, m->y, n, m->sw, b));                       // :78-81
-    GPC_TRY(launch_gpc_build_B(s, Kf.p, n_pad, m->sw, m->packed));           // :80
+    auto build_B = [&]() -> int { return launch_gpc_build_B(s, Kf.p, n_pad, m->sw, m->packed); };
+    GPC_TRY(build_B());                                                      // :80
     int info = 0;
-    GPC_TRY(factor_all(ctx, m->packed, n_pad, m->winv, &info, inv.p));
+    GPC_TRY(factor_all_or_refill(ctx, m->packed, n_pad, m->winv, &info, inv.p, build_B));
     if (info != 0) { free_model(m); set_error("GPC: I + sqrt(W) K sqrt(W) not positive definite"); return info; }
     GPC_TRY(launch_row_reduce(s, Kf.p, n_pad, n_pad, n_pad, b, t, red.p));  // K %*% b
     GPC_TRY(launch_gpc_scale(s, m->sw, t, t, n_pad));                        // sqrt(W) * .
@@ -1141,9 +1172,10 @@ int gprc_gpc_fit(gprc_ctx* ctx, int kernel, const double* params, int n_params, 
   }
   // final L from the converged f (:99-102), logq = objective - sum(diag(L)) (:103, sic)
   GPC_TRY(launch_gpc_pre(s, f, m->y, n, m->sw, b));
-  GPC_TRY(launch_gpc_build_B(s, Kf.p, n_pad, m->sw, m->packed));
+  auto build_B = [&]() -> int { return launch_gpc_build_B(s, Kf.p, n_pad, m->sw, m->packed); };
+  GPC_TRY(build_B());
   int info = 0;
-  GPC_TRY(factor_all(ctx, m->packed, n_pad, m->winv, &info));
+  GPC_TRY(factor_all_or_refill(ctx, m->packed, n_pad, m->winv, &info, nullptr, build_B));
   if (info != 0) { free_model(m); set_error("GPC: final factorisation failed"); return info; }
   double dsum = 0.0;
   GPC_TRY(launch_diag_sum(s, m->packed, n_pad, n, ctx->scal_dev));
@@ -1263,6 +1295,12 @@ int gprc_dev_factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* wi
   GPRC_TRY(use_device(ctx));
   if (!packed || !winv || !info_dev || n_pad <= 0 || n_pad % NB) { set_error("dev_factor_all: bad arguments"); return GPRC_ERR_ARG; }
   return factor_all_async(ctx, packed, n_pad, winv, info_dev, inv);
+}
+int gprc_factor_service(int on) {
+  const int was = g_service_off.load() ? 0 : 1;
+  if (on == 0) g_service_off.store(true);
+  else if (on > 0) g_service_off.store(false);
+  return was;
 }
 int gprc_dev_solve_prepare(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* inv, int64_t p_begin, int64_t p_end) {
   GPRC_TRY(use_device(ctx));

@@ -20,7 +20,7 @@ constexpr int MAX_PARAMS = 256;  // kernel parameters travel as kernel arguments
 constexpr int MAX_DEVICES = 64;  // per-device one-time setup flags
 // written to the LAPACK-info word by a fused kernel whose device-side dependency wait ran out (never seen in practice:
 // it takes a faulted or never-scheduled producer); hosts turn it into GPRC_ERR_HIP instead of using the factor
-constexpr int GPRC_INFO_WAIT_TIMEOUT = -99;
+// GPRC_INFO_WAIT_TIMEOUT (-99, include/gprc_native.h): what info becomes when a device-side dependency wait runs out
 static_assert(NB % NBI == 0 && NB >= NBI, "panel width must be a multiple of the 128 block");
 
 __host__ __device__ static inline int64_t pad_up(int64_t n, int64_t m) { return (n + m - 1) / m * m; }

@@ -868,6 +868,9 @@ __device__ __forceinline__ void panel_flag_wait(int* flag, PanelSync* sy, int* i
     int spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
       __builtin_amdgcn_s_sleep(2);
+      // somebody has already given up (e.g. a profiler that serialises dispatches keeps producer and consumer kernels apart): every
+      // later wait of the factorisation returns at once instead of running out its own bound
+      if ((spins & 255) == 0 && __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
       // exit condition every wave reaches (a producer that never publishes must not leave this workgroup spinning on the GPU
       // for ever; ~2^23 polls is several seconds, legitimate waits are below a millisecond): give up, let the grid drain, and tell
       // the host through the ONE word it always reads after a factorisation -- info = GPRC_INFO_WAIT_TIMEOUT (< 0; LAPACK infos are > 0)
@@ -899,6 +902,7 @@ __device__ __forceinline__ void panel_ready_wait(int* ctr, int need, PanelSync* 
     int spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
       __builtin_amdgcn_s_sleep(2);
+      if ((spins & 255) == 0 && __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
       if (++spins > (1 << 22)) {   // bounded (see panel_flag_wait): seconds, where the longest legitimate wait -- one trailing update at n <= 24576 -- is ~10 ms
         __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);

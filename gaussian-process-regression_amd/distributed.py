@@ -405,6 +405,15 @@ class DistributedGPR:
         if G == 1 and not self.lookahead and isinstance(comm, SingleComm) and hasattr(ops, "factor_all"):
             with ops.on(False):                               # one rank, nothing to exchange: the whole sweep natively
                 ops.factor_all(self.packed, self.winv, self.info)
+            if hasattr(ops, "L") and ops.read_info(self.info) == nat.INFO_WAIT_TIMEOUT and ops.L.gprc_factor_service(-1) == 1:
+                # the factor service's persistent launch and the sweep's kernels did not run concurrently (a tool that serialises
+                # dispatches, e.g. rocprofv3 --pmc): once per process, switch it off, rebuild the matrix and factor again
+                ops.L.gprc_factor_service(0)
+                with ops.on(False):
+                    self.info.zero_()
+                    for p in range(P):
+                        ops.fill_panel(X, self.packed, p)
+                    ops.factor_all(self.packed, self.winv, self.info)
             return self._finish_fit(y_pad)
         # F3 starts inside F2: the forward solve L z = y needs only panels <= p at step p, so it runs on an auxiliary
         # stream beside the trailing updates (128 latency-bound steps that would otherwise follow the sweep)
@@ -479,7 +488,8 @@ class DistributedGPR:
         ops, comm = self.ops, self.comm
         local_info = ops.read_info(self.info)
         if local_info < 0:   # a fused kernel's device-side dependency wait ran out (never seen; see gprc_internal.h): not a factor
-            raise nat.GprcError(nat.ERR_HIP, f"device-side dependency wait timed out on rank {comm.rank} (info = {local_info})")
+            raise nat.GprcError(nat.ERR_HIP, f"device-side dependency wait timed out on rank {comm.rank} (info = {local_info}); under a tool that "
+                                "serialises kernel dispatches (e.g. rocprofv3 --pmc) set GPRC_SERVICE=0")
         self.info_value = comm.min_positive(local_info)
         if self.info_value != 0:
             return self.info_value

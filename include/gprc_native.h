@@ -192,6 +192,14 @@ GPRC_API int gprc_dev_factor_subpanel(gprc_ctx* ctx, double* packed, int64_t n_p
  * info_dev: one device int, zeroed by the caller, receives LAPACK's info (first non-PD leading minor) if any.
  * inv: NULL, or gprc_solve_inv_size(n_pad) doubles that receive what gprc_dev_solve_prepare would compute for all panels. */
 GPRC_API int gprc_dev_factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev, double* inv);
+/* The factor service (one persistent launch carrying the panel chains beside the caller's kernels) needs kernels of two streams to
+ * run CONCURRENTLY.  Where they cannot -- a tool that serialises dispatches, e.g. rocprofv3 --pmc -- its device-side waits run out
+ * after a few seconds and info becomes GPRC_INFO_WAIT_TIMEOUT (-99).  The fit entry points (gprc_gpr_fit*, gprc_gpc_fit, ...) then
+ * switch the service off for the process, rebuild the matrix and factor again with one launch per panel; callers of
+ * gprc_dev_factor_all (asynchronous: info stays on the device) do the same with this switch: on = 0 off, 1 on, -1 query;
+ * returns the previous state.  (GPRC_SERVICE=0 in the environment never uses it.) */
+GPRC_API int gprc_factor_service(int on);
+#define GPRC_INFO_WAIT_TIMEOUT (-99)
 /* trailing update of panels q = q_begin, q_begin + q_stride, ... < q_end with factored panel p */
 GPRC_API int gprc_dev_update_trailing(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, int64_t q_begin,
                              int64_t q_end, int64_t q_stride);

@@ -468,3 +468,43 @@ def test_factor_schedules_are_bit_identical(monkeypatch):
         assert res[mode][2] == res["right"][2]
     ref = orc.gpr_fit(orc.RATQUAD, [0.8, 1.5], X, y, 0.1)
     assert nerr(res["1"][0], ref["L"]) <= TOL and nerr(res["1"][1], ref["alpha"]) <= TOL
+
+
+def test_two_contexts_fit_concurrently_on_one_gpu():
+    """Two host threads, each with its own context (own stream), fit and predict at the same time on the one GPU: every fit runs
+    its own factor service (a persistent launch waiting on counters that the same fit's other kernels feed) beside the other's.
+    The results are those of the same fits run one after the other, bit for bit."""
+    import threading
+    rng = np.random.default_rng(77)
+    probs = []
+    for n, l in ((3000, 0.7), (2600, 0.9)):
+        X = rng.uniform(-1, 1, (3, n)); y = rng.normal(size=n); Xs = rng.uniform(-1, 1, (3, 400))
+        probs.append((X, y, Xs, l))
+    ref = []
+    for X, y, Xs, l in probs:
+        g = GPR(X, y, 0.1, cov_func(sqrexp, l=l))
+        ref.append((g.alpha.copy(), g.logp, g.predict(Xs).copy()))
+        g.close()
+    out, errs = [None, None], []
+
+    def work(i):
+        try:
+            X, y, Xs, l = probs[i]
+            ctx = nat.Context(0)
+            res = []
+            for _ in range(6):
+                g = GPR(X, y, 0.1, cov_func(sqrexp, l=l), ctx=ctx)
+                res.append((g.alpha.copy(), g.logp, g.predict(Xs).copy()))
+                g.close()
+            out[i] = res
+            ctx.close()
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join(timeout=300) for t in ts]
+    assert not errs and all(o is not None for o in out), errs
+    for i in range(2):
+        for alpha, logp, pred in out[i]:
+            assert np.array_equal(alpha, ref[i][0]) and logp == ref[i][1] and np.array_equal(pred, ref[i][2]), i

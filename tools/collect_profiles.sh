@@ -6,6 +6,9 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/final; mkdir -p $out
 timeout -k 10 400 python3 bench.py > $out/bench_c4.log 2>&1; echo "bench rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kstats -- python3 bench.py --no-cpu-baseline > $out/kstats.log 2>&1; echo "kstats rc=$?"
+# counter collection serialises kernel dispatches: the factor service (a persistent launch beside the caller's kernels) cannot run
+# under it, so the PMC passes use one fused launch per panel instead -- the dominant kernel (solve_left_kernel, predict) is the same
+export GPRC_SERVICE=0
 W="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity-gate"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $W > $out/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $W > $out/pmc_write.log 2>&1; echo "pmc write rc=$?"
