@@ -508,3 +508,21 @@ def test_two_contexts_fit_concurrently_on_one_gpu():
     for i in range(2):
         for alpha, logp, pred in out[i]:
             assert np.array_equal(alpha, ref[i][0]) and logp == ref[i][1] and np.array_equal(pred, ref[i][2]), i
+
+
+def test_factor_service_switch_changes_no_bit():
+    """gprc_factor_service(0) makes every later factorisation of the process use one fused launch per panel (what the library
+    falls back to by itself where kernels cannot run concurrently, e.g. under rocprofv3 --pmc); same factor, same alpha, same
+    prediction, bit for bit; the switch reports its previous state."""
+    L = nat.lib()
+    rng = np.random.default_rng(78)
+    X = rng.uniform(-1, 1, (3, 2900)); y = rng.normal(size=2900); Xs = rng.uniform(-1, 1, (3, 300))
+    assert L.gprc_factor_service(-1) == 1
+    g = GPR(X, y, 0.1, cov_func(sqrexp, l=0.8)); a = (g.L.copy(), g.alpha.copy(), g.logp, g.predict(Xs).copy()); g.close()
+    try:
+        assert L.gprc_factor_service(0) == 1 and L.gprc_factor_service(-1) == 0
+        g = GPR(X, y, 0.1, cov_func(sqrexp, l=0.8)); b = (g.L.copy(), g.alpha.copy(), g.logp, g.predict(Xs).copy()); g.close()
+    finally:
+        assert L.gprc_factor_service(1) == 0
+    assert L.gprc_factor_service(-1) == 1
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3])
