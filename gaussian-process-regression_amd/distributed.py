@@ -209,10 +209,14 @@ class HipOps:
 
     def begin_fit(self):
         self._prepared = set()
+        self._solve_inv()
 
     def _solve_inv(self):
+        # uninitialised on purpose: a fill kernel queued on the main stream could run AFTER the auxiliary stream has written the
+        # first inverses; the solves read only what gprc_dev_solve_prepare has written
         if self.inv is None:
-            self.inv = self.zeros(int(self.L.gprc_solve_inv_size(self.geom.n_pad)))
+            with self.torch.cuda.stream(self.main_stream):
+                self.inv = self.torch.empty(int(self.L.gprc_solve_inv_size(self.geom.n_pad)), dtype=self.torch.float64, device=self.device)
         return self.inv
 
     def _prepare(self, ctx, packed, winv, panels):
