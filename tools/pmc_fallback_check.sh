@@ -1,3 +1,5 @@
+# On the GPU box: what happens where kernel dispatches are serialised (rocprofv3 --pmc): the fit entry points and bench.py fall back to one
+# launch per panel by themselves (gprc_factor_service); logs under gpurun_out/pmc_test/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/pmc_test
 timeout -k 10 300 python -m pytest tests/test_gpu_device_level.py tests/test_gpu_parity.py -x -q > gpurun_out/dl.log 2>&1; tail -2 gpurun_out/dl.log
 (time timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_test/a -- python3 bench.py --workload c2 --steps 1 --warmup 0 --no-cpu-baseline) > gpurun_out/pmc_test/bench_c2_pmc.log 2>&1
