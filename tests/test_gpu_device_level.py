@@ -114,6 +114,38 @@ def test_grouped_left_looking_with_the_service_inside_the_groups(monkeypatch):
     ctx.close()
 
 
+def test_factor_service_over_many_panel_counts(monkeypatch):
+    """Every panel count from 2 to 14 and a few larger ones, including 41 (n_pad = 20992: the first size that the default schedule
+    takes in groups), each under the default grouping and under small groups: the whole-sweep call against the launch-per-panel
+    sweep, bitwise.  (The tile enumeration of the service's update kernel, its ticketed head and the group boundaries all depend
+    on the panel count.)"""
+    sizes = [512 * P - 37 for P in range(2, 15)] + [512 * 19, 512 * 27 - 300, 512 * 41 - 5]
+    for n in sizes:
+        L, ctx, g, K = _filled(n, seed=n % 97)
+        P = g.P
+        a = K.clone(); w, info = _new(g)
+        for p in range(P):
+            nat.check(L.gprc_dev_factor_panel(ctx.handle, a.data_ptr(), g.n_pad, p, w.data_ptr(), info.data_ptr()))
+            if p + 1 < P:
+                nat.check(L.gprc_dev_update_trailing(ctx.handle, a.data_ptr(), g.n_pad, p, p + 1, P, 1))
+        torch.cuda.synchronize()
+        assert int(info[0]) == 0, n
+        for want in (None, "400"):
+            if want is None:
+                monkeypatch.delenv("GPRC_FACTOR", raising=False)
+            else:
+                monkeypatch.setenv("GPRC_FACTOR", want)
+            b = K.clone(); w2, info2 = _new(g)
+            nat.check(L.gprc_dev_factor_all(ctx.handle, b.data_ptr(), g.n_pad, w2.data_ptr(), info2.data_ptr(), NULL))
+            torch.cuda.synchronize()
+            assert int(info2[0]) == 0, (n, want)
+            assert torch.equal(b, a) and torch.equal(w2, w), (n, want)
+            del b, w2
+        ctx.close()
+        del a, w, K
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("n", [600, 1100, 1536, 9100])
 def test_factor_service_is_bit_identical_to_the_launch_per_panel_sweep(n):
     """gprc_dev_factor_all at these sizes is the factor service (one persistent launch carrying every panel's dependent chain,
