@@ -187,8 +187,8 @@ GPRC_API int gprc_dev_factor_panel(gprc_ctx* ctx, double* packed, int64_t n_pad,
 GPRC_API int gprc_dev_factor_subpanel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, int j, int part, double* winv,
                              int* info_dev);
 /* All panels of an already filled packed matrix on ONE GPU, asynchronously on the context's stream (the one-rank form of
- * the factor_panel / update_trailing sweep; the factor service up to n_pad = 24576, the grouped left-looking schedule beyond):
- * results bit-identical to that sweep.
+ * the factor_panel / update_trailing sweep: the panels in groups, a left-looking pass per group, the factor service inside
+ * the group; one group below n_pad = 20480): results bit-identical to that sweep.
  * info_dev: one device int, zeroed by the caller, receives LAPACK's info (first non-PD leading minor) if any.
  * inv: NULL, or gprc_solve_inv_size(n_pad) doubles that receive what gprc_dev_solve_prepare would compute for all panels. */
 GPRC_API int gprc_dev_factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev, double* inv);
@@ -215,13 +215,15 @@ GPRC_API int gprc_dev_update_range(gprc_ctx* ctx, double* packed, int64_t n_pad,
 GPRC_API int64_t gprc_solve_inv_size(int64_t n_pad);
 GPRC_API int gprc_dev_solve_prepare(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* inv, int64_t p_begin,
                            int64_t p_end);
-/* b := L^-1 b (transpose == 0) or L^-T b (transpose != 0), one launch per panel; work: gprc_trsv_work_size(n_pad) doubles */
+/* b := L^-1 b (transpose == 0) or L^-T b (transpose != 0), one launch per panel (launch p: the product of panel p and the
+ * diagonal step of the next panel); work: gprc_trsv_work_size(n_pad) doubles */
 GPRC_API int64_t gprc_trsv_work_size(int64_t n_pad);
 GPRC_API int gprc_dev_trsv(gprc_ctx* ctx, const double* packed, const double* inv, int64_t n_pad, double* b, int transpose,
                   double* work);
-/* one panel step of that solve (forward: p = 0, 1, ...; transposed: p = P-1, ..., 0): the forward solve needs only
- * panels <= p, so a sweep that produces the panels in order can run it beside the factorisation.  The same launch as inside
- * gprc_dev_trsv: identical bits.  work as above (one buffer for the whole sequence of steps). */
+/* one panel step of that solve (forward: p = 0, 1, ...; transposed: p = P-1, ..., 0): x_p, then its contribution to the
+ * rest of the right-hand side.  The forward solve needs only panels <= p, so a sweep that produces the panels in order can
+ * run it beside the factorisation.  Element by element the arithmetic of gprc_dev_trsv: identical bits.  work as above (one
+ * buffer for the whole sequence of steps). */
 GPRC_API int gprc_dev_trsv_step(gprc_ctx* ctx, const double* packed, const double* inv, int64_t n_pad, double* b, int transpose,
                        int64_t p, double* work);
 /* vt (m_pad x n_pad, leading dimension ld >= m_pad, ld even, m_pad % 128 == 0) = K(X_star, X), zero in the
