@@ -122,6 +122,20 @@ namespace {
 
 thread_local gprc_ctx* g_cur_ctx = nullptr;  // set by use_device(): whose pool the scoped temporaries below use
 
+// Contexts that exist.  A model may outlive its context (a host language's garbage collector finalising objects in arbitrary order
+// at exit: Python does): gprc_model_free then must not touch the context's stream or block pool.
+static std::mutex g_live_mu;
+static std::vector<const gprc_ctx*> g_live_ctx;
+static void ctx_register(const gprc_ctx* c) { std::lock_guard<std::mutex> lk(g_live_mu); g_live_ctx.push_back(c); }
+static void ctx_unregister(const gprc_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  g_live_ctx.erase(std::remove(g_live_ctx.begin(), g_live_ctx.end(), c), g_live_ctx.end());
+}
+static bool ctx_alive(const gprc_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  return std::find(g_live_ctx.begin(), g_live_ctx.end(), c) != g_live_ctx.end();
+}
+
 int pool_alloc(gprc_ctx* ctx, size_t bytes, void** out) {
   if (bytes == 0) bytes = 8;
   if (ctx) {
@@ -808,12 +822,14 @@ int gprc_ctx_create(int device, void* stream, gprc_ctx** ctx_out) {
     const long long v = std::atoll(cb);
     if (v > 0) ctx->chunk_bytes = (size_t)v;
   }
+  ctx_register(ctx);
   *ctx_out = ctx;
   return 0;
 }
 
 int gprc_ctx_destroy(gprc_ctx* ctx) {
   if (!ctx) return 0;
+  ctx_unregister(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < 4; ++i)
@@ -1097,7 +1113,12 @@ int gprc_gpr_get_noise(gprc_model* m, double* noise_out) {
   return 0;
 }
 int gprc_model_free(gprc_model* m) {
-  if (m && m->ctx && m->ctx->stream) (void)hipStreamSynchronize(m->ctx->stream);
+  if (!m) return 0;
+  if (m->ctx && !ctx_alive(m->ctx)) {   // the context went first: its stream is gone (and was synchronised), its pool too
+    m->ctx = nullptr;                   // -> the buffers go straight back to the driver
+    (void)hipDeviceSynchronize();
+  }
+  if (m->ctx && m->ctx->stream) (void)hipStreamSynchronize(m->ctx->stream);
   free_model(m);
   return 0;
 }

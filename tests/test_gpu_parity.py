@@ -526,3 +526,27 @@ def test_factor_service_switch_changes_no_bit():
         assert L.gprc_factor_service(1) == 0
     assert L.gprc_factor_service(-1) == 1
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3])
+
+
+def test_a_model_may_outlive_its_context():
+    """A host language's garbage collector may finalise a context before the models fitted on it (Python does so at interpreter
+    exit when both hang off module globals): gprc_model_free then must leave the dead context's stream and block pool alone.  In a
+    child process, because the failure mode was a segmentation fault."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import gprc_amd\n"
+        "from gprc_amd import GPR, GPC, cov_func, sqrexp, _native as nat\n"
+        "rng = np.random.default_rng(1); X = rng.uniform(-1, 1, (2, 700)); y = rng.normal(size=700)\n"
+        "ctx = nat.Context(0)\n"
+        "g = GPR(X, y, 0.1, cov_func(sqrexp, l=0.7), ctx=ctx)\n"
+        "c = GPC(X, np.where(y > 0, 1.0, -1.0), cov_func(sqrexp, l=0.7), 1e-5, ctx=ctx, reference_stop=False)\n"
+        "ctx.close()\n"
+        "g.close(); c.close()\n"
+        "g2 = GPR(X, y, 0.1, cov_func(sqrexp, l=0.7))\n"
+        "print('OUTLIVED-OK', g2.logp)\n") % (os.path.dirname(here),)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OUTLIVED-OK" in r.stdout, (r.returncode, r.stderr[-1500:])
