@@ -550,3 +550,26 @@ def test_a_model_may_outlive_its_context():
         "print('OUTLIVED-OK', g2.logp)\n") % (os.path.dirname(here),)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OUTLIVED-OK" in r.stdout, (r.returncode, r.stderr[-1500:])
+
+
+def test_not_positive_definite_through_the_factor_service():
+    """A singular matrix over several panels (constant kernel, noise 0: K = 1 1^T, second pivot exactly 0): the factor service and
+    everything that waits on it run to completion on garbage (every flag is published whatever the numbers are), the call returns
+    LAPACK's info = 2 promptly, and GPR$new's jitter loop (R/GPRclass.R:140-149) then succeeds with a changed noise."""
+    import time
+    rng = np.random.default_rng(3)
+    n = 2600
+    X = rng.uniform(-1, 1, (2, n)); y = rng.normal(size=n)
+    ctx = nat.default_context()
+    _, pp, npar = nat.params_array([1.0])
+    model = C.c_void_p()
+    Xf = np.asfortranarray(X)
+    t0 = time.time()
+    rc = nat.lib().gprc_gpr_fit(ctx.handle, nat.CONSTANT, pp, npar, Xf.ctypes.data, 2, n, y.ctypes.data, 0.0, C.byref(model))
+    assert rc == 2 and time.time() - t0 < 5.0
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        g = GPR(X, y, 0.0, cov_func(constant, c=1.0))
+    assert g.noise > 0 and any("Noise got changed" in str(x.message) for x in w)
+    assert np.all(np.isfinite(g.alpha))
+    g.close()
