@@ -258,9 +258,10 @@ __device__ __forceinline__ void potf2_phase_c_block(double* S, const double* Wd,
 // ptr (may be null; GPRC_POTF2_TRACE): s_memrealtime stamps of thread 0 -- [0] entry, [1] block loaded, [2] first 16x16 sweep done,
 // [3 + 2 s] / [4 + 2 s] after the two barriers of step s, [19] exit (stores issued).  Measurement only.
 #define POTF2_STAMP(k) do { if (ptr && threadIdx.x == 0) ptr[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// preloaded: S already holds the block (gemm_tile_128<.., LDSOUT>), the loads from A are skipped.
 template <int NW>
 __device__ __attribute__((noinline)) void potf2_blocked_body(double* sm, double* A, int64_t lda, double* winv, int* info, int col0,
-                                                             unsigned long long* ptr = nullptr) {
+                                                             unsigned long long* ptr = nullptr, bool preloaded = false) {
   static_assert(NW >= 8, "phase B needs one wave per task: 7 tasks per step");
   constexpr int TYS = NW / 2;          // column groups of the 128-row load / store loops (NW * 64 threads / 128 rows)
   double* S = sm;                      // PB x BLD
@@ -270,7 +271,7 @@ __device__ __attribute__((noinline)) void potf2_blocked_body(double* sm, double*
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int q = lane >> 4, r = lane & 15;
   POTF2_STAMP(0);
-  {
+  if (!preloaded) {
     // all the loads of a thread's 128 / TYS columns are issued before the first LDS store (the loop with one conditional load
     // per iteration took 4 us of a 46-us block); entries above the diagonal are read too -- allocated storage -- and dropped
     const int i = t & 127, ty = t >> 7;
@@ -416,10 +417,14 @@ __device__ __forceinline__ const double* strip_ktile(const double* B, int64_t ld
 // tile's 128 rows over its 128 columns -- these columns of v^T are final after this tile, so colSums(v * v)
 // (R/GPRclass.R:164) is assembled from these per-block partials and the pass that re-read the whole solved chunk is gone.
 // Fixed order: a lane's 16 columns (n, r ascending), the four lanes of a row (xor 16, xor 32), the two column waves.
-template <bool SET, bool SEG = false, bool SEGA = false, bool SSQ = false>
+// LDSOUT: the finished tile ALSO goes to lds_out as the 128 x 128 LDS image potf2_blocked_body works on (leading dimension 144,
+// zero above the diagonal) -- the factor role hands the updated diagonal block to the factorisation without the round trip
+// through memory (one more workgroup barrier than without: every wave must be past its last operand read, the image overlaps
+// the staging buffers).
+template <bool SET, bool SEG = false, bool SEGA = false, bool SSQ = false, bool LDSOUT = false>
 __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                                               int64_t ldb, int K, double* smem, int64_t brow = 0, int64_t arow = 0, int kt0 = 0,
-                                              double* ssq = nullptr, int tid = -1) {
+                                              double* ssq = nullptr, int tid = -1, double* lds_out = nullptr) {
   const int t = tid < 0 ? (int)threadIdx.x : tid, lane = t & 63;   // tid: a 256-thread team inside a larger workgroup
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -521,6 +526,20 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int m = 0; m < 4; ++m) Cw[m * 16 + (int64_t)(n * 16 + 4 * r) * ldc] = acc[m][n][r];
+
+  if constexpr (LDSOUT) {
+    __syncthreads();  // every wave is past its last operand read: the staging buffers are free
+    constexpr int LDO = 144;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int row = wr * 64 + fr + m * 16, col = wc * 64 + fk + n * 16 + 4 * r;
+          lds_out[row + col * LDO] = (row >= col) ? acc[m][n][r] : 0.0;
+        }
+  }
 
   if constexpr (SSQ) {
     double rs[4];
@@ -942,7 +961,7 @@ __device__ __forceinline__ void panel_factor_role(double* sm, double* pan, int64
   PANEL_STAMP(0);
   for (int j = 0; j < TPP; ++j) {
     potf2_blocked_body<8>(sm, pan + (int64_t)j * NBI + (int64_t)j * NBI * ld, ld, wp + (int64_t)j * NBI * NBI, info, p * NB + j * NBI,
-                          (ptrace && j == 1) ? ptrace : nullptr);
+                          (ptrace && j == 1) ? ptrace : nullptr, j > 0);   // blocks 1..3 arrive in LDS from the update tile below
     PANEL_STAMP(1 + 6 * j);
     panel_flag_publish(&sy->W[j]);               // (its vmcnt(0) + barrier also make L(j,j) / Winv_j visible to this workgroup's own DMA)
     PANEL_STAMP(2 + 6 * j);
@@ -957,10 +976,11 @@ __device__ __forceinline__ void panel_factor_role(double* sm, double* pan, int64
     PANEL_STAMP(4 + 6 * j);
     panel_flag_publish(&sy->R[j + 1]);           // rows of strip j+1 left of its diagonal block are final
     PANEL_STAMP(5 + 6 * j);
-    if (team == 0) gemm_tile_128<false>(Dn, ld, Cn, ld, Cn, ld, 128, sm, 0, 0, 0, nullptr, tid);
-    else gemm_tile_shadow_barriers(128);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                             // the updated block is reloaded by all 8 waves in potf2
+    // the updated block goes to memory (its upper triangle is part of the packed matrix's bits) AND, as potf2's LDS image, straight
+    // to the factorisation: no wait for the stores, no reload (5 + 1.5 us per diagonal block)
+    if (team == 0) gemm_tile_128<false, false, false, false, true>(Dn, ld, Cn, ld, Cn, ld, 128, sm, 0, 0, 0, nullptr, tid, sm);
+    else { gemm_tile_shadow_barriers(128); __builtin_amdgcn_s_barrier(); }
+    __syncthreads();                             // the image is complete for all 8 waves
     PANEL_STAMP(6 + 6 * j);
   }
 }
