@@ -275,7 +275,7 @@ __device__ __attribute__((noinline)) void potf2_blocked_body(double* sm, double*
     // all the loads of a thread's 128 / TYS columns are issued before the first LDS store (the loop with one conditional load
     // per iteration took 4 us of a 46-us block); entries above the diagonal are read too -- allocated storage -- and dropped
     const int i = t & 127, ty = t >> 7;
-    constexpr int BATCH = 16;                       // loads in flight per thread (32 VGPRs)
+    constexpr int BATCH = (NW == 8) ? 32 : 16;      // loads in flight per thread (the 16-wave kernel is capped at 128 VGPRs)
     for (int k0 = 0; k0 < PB / TYS; k0 += BATCH) {
       double v[BATCH];
 #pragma unroll

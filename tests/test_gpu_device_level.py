@@ -28,12 +28,25 @@ def _filled(n, d=3, seed=31):
     return L, ctx, g, packed
 
 
+def _clone(t):
+    """A copy that is COMPLETE before the library touches it: the context below runs on the library's own (non-blocking) stream, which
+    is not ordered with torch's; without the synchronisation a large copy is still in flight when the first kernel starts (seen
+    once at n = 20987: the copy overwrote the tail panels' first updates)."""
+    c = t.clone()
+    torch.cuda.synchronize()
+    return c
+
+
 def _new(g):
-    return (torch.zeros(g.winv_size, dtype=torch.float64, device="cuda"), torch.zeros(4, dtype=torch.int32, device="cuda"))
+    r = (torch.zeros(g.winv_size, dtype=torch.float64, device="cuda"), torch.zeros(4, dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()
+    return r
 
 
 def _new_inv(g):
-    return torch.full((int(nat.lib().gprc_solve_inv_size(g.n_pad)),), float("nan"), dtype=torch.float64, device="cuda")
+    r = torch.full((int(nat.lib().gprc_solve_inv_size(g.n_pad)),), float("nan"), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    return r
 
 
 NULL = None
@@ -45,7 +58,7 @@ def test_sweep_variants_are_bit_identical():
     P = g.P
 
     def basic():                                         # factor_panel + one update per panel
-        a = K.clone(); w, info = _new(g)
+        a = _clone(K); w, info = _new(g)
         for p in range(P):
             nat.check(L.gprc_dev_factor_panel(ctx.handle, a.data_ptr(), g.n_pad, p, w.data_ptr(), info.data_ptr()))
             if p + 1 < P:
@@ -54,7 +67,7 @@ def test_sweep_variants_are_bit_identical():
         return a, w, int(info[0])
 
     def quarters_and_ranges(batch):                      # factor in 4 x (part 1, part 2); far panels updated in batches
-        a = K.clone(); w, info = _new(g)
+        a = _clone(K); w, info = _new(g)
         far_from = 0
         for p in range(P):
             if p > 0:                                    # bring panel p up to date, whatever has not been applied yet
@@ -69,7 +82,7 @@ def test_sweep_variants_are_bit_identical():
         return a, w, int(info[0])
 
     def whole():
-        a = K.clone(); w, info = _new(g)
+        a = _clone(K); w, info = _new(g)
         nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr(), NULL))
         torch.cuda.synchronize()
         return a, w, int(info[0])
@@ -79,7 +92,7 @@ def test_sweep_variants_are_bit_identical():
     for name, got in (("batch 1", quarters_and_ranges(1)), ("batch 3", quarters_and_ranges(3)), ("factor_all", whole())):
         assert got[2] == 0 and torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), name
     with pytest.raises(nat.GprcError, match="behind the source range"):
-        nat.check(L.gprc_dev_update_range(ctx.handle, K.clone().data_ptr(), g.n_pad, 0, 3, 2, P, 1))
+        nat.check(L.gprc_dev_update_range(ctx.handle, _clone(K).data_ptr(), g.n_pad, 0, 3, 2, P, 1))
     ctx.close()
 
 
@@ -90,7 +103,7 @@ def test_grouped_left_looking_with_the_service_inside_the_groups(monkeypatch):
     n = 9100
     L, ctx, g, K = _filled(n, seed=6)
     P = g.P
-    a = K.clone(); w, info = _new(g)
+    a = _clone(K); w, info = _new(g)
     for p in range(P):
         nat.check(L.gprc_dev_factor_panel(ctx.handle, a.data_ptr(), g.n_pad, p, w.data_ptr(), info.data_ptr()))
         if p + 1 < P:
@@ -100,7 +113,7 @@ def test_grouped_left_looking_with_the_service_inside_the_groups(monkeypatch):
     inv_ref = None
     for want in ("1", "500", "1500", "right"):
         monkeypatch.setenv("GPRC_FACTOR", want)
-        b = K.clone(); w2, info2 = _new(g); inv2 = _new_inv(g)
+        b = _clone(K); w2, info2 = _new(g); inv2 = _new_inv(g)
         nat.check(L.gprc_dev_factor_all(ctx.handle, b.data_ptr(), g.n_pad, w2.data_ptr(), info2.data_ptr(), inv2.data_ptr()))
         torch.cuda.synchronize()
         assert int(info2[0]) == 0, want
@@ -123,7 +136,7 @@ def test_factor_service_over_many_panel_counts(monkeypatch):
     for n in sizes:
         L, ctx, g, K = _filled(n, seed=n % 97)
         P = g.P
-        a = K.clone(); w, info = _new(g)
+        a = _clone(K); w, info = _new(g)
         for p in range(P):
             nat.check(L.gprc_dev_factor_panel(ctx.handle, a.data_ptr(), g.n_pad, p, w.data_ptr(), info.data_ptr()))
             if p + 1 < P:
@@ -135,7 +148,7 @@ def test_factor_service_over_many_panel_counts(monkeypatch):
                 monkeypatch.delenv("GPRC_FACTOR", raising=False)
             else:
                 monkeypatch.setenv("GPRC_FACTOR", want)
-            b = K.clone(); w2, info2 = _new(g)
+            b = _clone(K); w2, info2 = _new(g)
             nat.check(L.gprc_dev_factor_all(ctx.handle, b.data_ptr(), g.n_pad, w2.data_ptr(), info2.data_ptr(), NULL))
             torch.cuda.synchronize()
             assert int(info2[0]) == 0, (n, want)
@@ -154,7 +167,7 @@ def test_factor_service_is_bit_identical_to_the_launch_per_panel_sweep(n):
     flags are per call).  2, 3, 3 (no padding) and 18 panels."""
     L, ctx, g, K = _filled(n, seed=5)
     P = g.P
-    a = K.clone(); w, info = _new(g)
+    a = _clone(K); w, info = _new(g)
     for p in range(P):
         nat.check(L.gprc_dev_factor_panel(ctx.handle, a.data_ptr(), g.n_pad, p, w.data_ptr(), info.data_ptr()))
         if p + 1 < P:
@@ -162,7 +175,7 @@ def test_factor_service_is_bit_identical_to_the_launch_per_panel_sweep(n):
     torch.cuda.synchronize()
     assert int(info[0]) == 0
     for rep in range(2):
-        b = K.clone(); w2, info2 = _new(g)
+        b = _clone(K); w2, info2 = _new(g)
         inv2 = _new_inv(g) if rep else None      # with and without the explicit diagonal inverses riding along
         nat.check(L.gprc_dev_factor_all(ctx.handle, b.data_ptr(), g.n_pad, w2.data_ptr(), info2.data_ptr(), inv2.data_ptr() if rep else NULL))
         torch.cuda.synchronize()
@@ -201,17 +214,17 @@ def test_solve_in_panel_steps_is_bit_identical(n, reps):
     work = torch.zeros(g.trsv_work, dtype=torch.float64, device="cuda")
     work2 = torch.zeros(g.trsv_work, dtype=torch.float64, device="cuda")
     for transpose in (0, 1):
-        steps = b0.clone()
+        steps = _clone(b0)
         order = range(g.P) if not transpose else range(g.P - 1, -1, -1)
         for p in order:
             nat.check(L.gprc_dev_trsv_step(ctx.handle, a.data_ptr(), inv.data_ptr(), g.n_pad, steps.data_ptr(), transpose, p, work2.data_ptr()))
         for _ in range(reps):
-            whole = b0.clone()
+            whole = _clone(b0)
             nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), inv.data_ptr(), g.n_pad, whole.data_ptr(), transpose, work.data_ptr()))
             torch.cuda.synchronize()
             assert torch.equal(whole, steps)
     # and it is a solve: L (L^T x) = b
-    x = b0.clone()
+    x = _clone(b0)
     nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), inv.data_ptr(), g.n_pad, x.data_ptr(), 0, work.data_ptr()))
     nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), inv.data_ptr(), g.n_pad, x.data_ptr(), 1, work.data_ptr()))
     torch.cuda.synchronize()
@@ -240,10 +253,10 @@ def test_solve_in_panel_steps_is_bit_identical_at_a_large_size():
     work = torch.zeros(g.trsv_work, dtype=torch.float64, device="cuda")
     work2 = torch.zeros(g.trsv_work, dtype=torch.float64, device="cuda")
     for transpose in (0, 1):
-        steps = b0.clone()
+        steps = _clone(b0)
         for p in (range(g.P) if not transpose else range(g.P - 1, -1, -1)):
             nat.check(L.gprc_dev_trsv_step(ctx.handle, a.data_ptr(), inv.data_ptr(), g.n_pad, steps.data_ptr(), transpose, p, work2.data_ptr()))
-        whole = b0.clone()
+        whole = _clone(b0)
         nat.check(L.gprc_dev_trsv(ctx.handle, a.data_ptr(), inv.data_ptr(), g.n_pad, whole.data_ptr(), transpose, work.data_ptr()))
         torch.cuda.synchronize()
         assert torch.equal(whole, steps), transpose
