@@ -321,6 +321,9 @@ __device__ __attribute__((noinline)) void potf2_blocked_body(double* sm, double*
     } else {
       for (int b = wave; b < total; b += NW - 1) potf2_phase_c_block(S, Wd, s, c0, m, b, lane, q, r);
     }
+    // (a preloaded block's stores to memory -- gemm_tile_128<.., LDSOUT> did not wait for them -- are complete in every wave before
+    // this barrier, hence before any wave stores the factored block over them below; free after the first step)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     POTF2_STAMP(4 + 2 * s);
   }
