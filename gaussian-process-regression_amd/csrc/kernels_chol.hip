@@ -972,13 +972,14 @@ __device__ __forceinline__ void panel_factor_role(double* sm, double* pan, int64
     // the two tiles the next diagonal block is waiting for, by team 0 (team 1 shadows the barriers)
     double* Cn = pan + (int64_t)(j + 1) * NBI + (int64_t)j * NBI * ld;            // block (j+1, j)
     double* Dn = pan + (int64_t)(j + 1) * NBI + (int64_t)(j + 1) * NBI * ld;      // block (j+1, j+1)
-    if (j > 0) panel_flag_wait(&sy->E[j + 1], sy, info);                          // their updates with the columns left of block j
+    if (j > 0) panel_ready_wait(&sy->E[j + 1], 1, sy, info);                      // block (j+1, j): its update with the columns left of block j
     PANEL_STAMP(3 + 6 * j);
     if (team == 0) gemm_tile_128<true>(Cn, ld, Cn, ld, wp + (int64_t)j * NBI * NBI, 128, 128, sm, 0, 0, 0, nullptr, tid);
     else gemm_tile_shadow_barriers(128);
     PANEL_STAMP(4 + 6 * j);
     panel_flag_publish(&sy->R[j + 1]);           // rows of strip j+1 left of its diagonal block are final
     PANEL_STAMP(5 + 6 * j);
+    if (j > 0) panel_ready_wait(&sy->E[j + 1], 2, sy, info);                      // block (j+1, j+1): likewise
     // the updated block goes to memory (its upper triangle is part of the packed matrix's bits) AND, as potf2's LDS image, straight
     // to the factorisation: no wait for the stores, no reload (5 + 1.5 us per diagonal block)
     if (team == 0) gemm_tile_128<false, false, false, false, true>(Dn, ld, Cn, ld, Cn, ld, 128, sm, 0, 0, 0, nullptr, tid, sm);
@@ -1025,12 +1026,14 @@ __device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int6
     const int64_t K = (int64_t)(s - 1) * NBI;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my own L(s, 0..s-2): every wave's stores, then the barrier
     __syncthreads();
-    // the diagonal block first: it needs my own rows only, so it runs while strip s-1's rows are still on their way
-    gemm_tile_128<false>(pan + (int64_t)s * 128 + (int64_t)s * NBI * ld, ld, Arow, ld, Arow, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
-    __syncthreads();
+    // block (s, s-1) first: the factor role's solve tile is the next thing on the chain that needs this strip (E_s = 1); block (s, s),
+    // which its update tile preloads one tile later, second (E_s = 2).  (The other order -- (s, s) needs my own rows only and can run
+    // before R_{s-1} -- left the factor role waiting 13 us for E_3 in every panel.)
     panel_flag_wait(&sy->R[s - 1], sy, info);
     gemm_tile_128<false>(pan + (int64_t)s * 128 + K * ld, ld, Arow, ld, pan + K, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
-    panel_flag_publish(&sy->E[s]);
+    panel_count_publish(&sy->E[s], 1);
+    gemm_tile_128<false>(pan + (int64_t)s * 128 + (int64_t)s * NBI * ld, ld, Arow, ld, Arow, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
+    panel_count_publish(&sy->E[s], 1);
   }
 }
 
