@@ -78,9 +78,8 @@ struct gprc_ctx {
   int* info_dev = nullptr;     // LAPACK info written by the diagonal-block kernel
   void* sync_dev = nullptr;    // 64 bytes of flags for the fused panel kernel (zeroed before every launch, stream-ordered)
                                // + another 64 for launches on the look-ahead stream
-  // one-GPU look-ahead (factor_all_async): the panel chain runs on a high-priority side stream beside the trailing update
+  // the factor service's persistent launch runs on a high-priority side stream beside the caller's kernels (factor_group_service)
   hipStream_t side_stream = nullptr;
-  hipStream_t upd_stream = nullptr;   // CU-masked stream of the bulk trailing updates while a look-ahead sweep runs (see factor_all_lookahead)
   void* svc_trace = nullptr;          // GPRC_SERVICE_TRACE: 16 stamps x SVC_TRACE_PANELS of the last factor-service sweep (measurement)
   hipEvent_t ev_pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned ev_next = 0;
@@ -333,83 +332,6 @@ int stream_after(gprc_ctx* ctx, hipStream_t to, hipStream_t from) {
   return 0;
 }
 
-// Right-looking sweep with LOOK-AHEAD on one GPU: the chain that factors panel p + 1 (one fused launch: a handful of
-// latency-bound workgroups) runs on a high-priority side stream while the main stream is still applying panel p to the
-// panels behind p + 1.  Same launches on the same data as the plain right-looking sweep -- only their overlap differs --
-// so the factor is bit-identical.  It pays where the chain is a large share of the fit (n <= ~16k: at n = 8192 the chain
-// is 6.6 of 12.3 ms, at n = 16384 14 of 44 ms per Cholesky); beyond that the grouped left-looking schedule below wins.
-int factor_all_lookahead(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev) {
-  hipStream_t s = ctx->stream;
-  const int64_t P = n_pad / NB;
-  // The chain's workgroups need a whole CU each (149 KB of LDS) and the trailing update keeps every CU busy with two GEMM
-  // workgroups, so on shared CUs the chain crawls (measured: 0.42 -> 0.96 ms per panel at n = 16384) and the overlap buys
-  // little.  GPRC_LA_MASK = r sets r CUs out of every 32 aside for the chain: the side stream is created with that CU
-  // mask, the bulk updates of the sweep go to a stream with the complementary mask.  Default 0 (no masks: one priority
-  // stream beside the caller's) because the masks measured WORSE on MI355X: kernels on a CU-masked stream lose far
-  // more than the masked share (trailing update 43 -> 22 / 31 / 29 TFLOP/s with 2 / 4 / 8 of 32 CUs set aside; fit at
-  // n = 8192: 12.2 -> 14.6 / 13.5 / 13.3 ms; GPC iteration at n = 16384: 41.7 -> 54.2 / 42.0 / 42.0 ms).
-  static const int reserve = [] { const char* e = std::getenv("GPRC_LA_MASK"); const int v = e ? std::atoi(e) : 0; return v < 0 || v > 16 ? 0 : v; }();
-  if (!ctx->side_stream) {
-    bool masked = false;
-    if (reserve > 0) {
-      hipDeviceProp_t prop;
-      GPRC_HIP(hipGetDeviceProperties(&prop, ctx->device));
-      const int words = (prop.multiProcessorCount + 31) / 32;
-      std::vector<uint32_t> chain(words, 0u), bulk(words, 0u);
-      for (int w = 0; w < words; ++w)
-        for (int b = 0; b < 32; ++b) {
-          if (w * 32 + b >= prop.multiProcessorCount) break;
-          // every (32 / reserve)-th CU: whatever the bit -> (XCD, shader engine) mapping is, the chain's CUs are spread evenly
-          const bool mine = (b % (32 / reserve)) == (32 / reserve) - 1 && (b / (32 / reserve)) < reserve;
-          (mine ? chain : bulk)[w] |= 1u << b;
-        }
-      hipError_t e1 = hipExtStreamCreateWithCUMask(&ctx->side_stream, (uint32_t)words, chain.data());
-      hipError_t e2 = e1 == hipSuccess ? hipExtStreamCreateWithCUMask(&ctx->upd_stream, (uint32_t)words, bulk.data()) : e1;
-      masked = e1 == hipSuccess && e2 == hipSuccess;
-      if (!masked) {
-        (void)hipGetLastError();
-        if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); ctx->side_stream = nullptr; }
-        ctx->upd_stream = nullptr;
-      }
-    }
-    if (!masked) {
-      int lo = 0, hi = 0;
-      GPRC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      GPRC_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi));
-    }
-  }
-  hipStream_t side = ctx->side_stream;
-  hipStream_t bulk = ctx->upd_stream ? ctx->upd_stream : s;   // where the updates run
-  void* sync_side = static_cast<char*>(ctx->sync_dev) + 256;
-  if (bulk != s) GPRC_TRY(stream_after(ctx, bulk, s));
-  GPRC_TRY(stream_after(ctx, side, s));                       // the fill (and the caller's memset of info) precede the chain
-  GPRC_TRY(launch_panel_fused(side, packed, n_pad, 0, winv, info_dev, sync_side));
-  // Optional batched far updates (GPRC_LA_BATCH = b > 1, as the multi-rank sweep does): only the panel factored next is
-  // brought up to date at every step; the panels behind it receive the factored panels every b steps in ONE pass with the C
-  // tiles held in the accumulators.  Bit-identical, but measured SLOWER on one GPU -- the catch-up of the next panel
-  // (K up to 512 b on a single panel) sits on the critical path: fit at n = 8192 12.1 -> 12.9 ms, GPC iteration at
-  // n = 16384 41.9 -> 42.9 (b = 4) / 45.5 ms (b = 8).  Default 1: per panel.
-  static const int64_t batch = [] { const char* e = std::getenv("GPRC_LA_BATCH"); const long long v = e ? std::atoll(e) : 1; return v < 1 ? 1LL : v; }();
-  auto update = [&](int64_t p0, int64_t p1, int64_t q0, int64_t q1) -> int {   // panels [p0, p1) -> targets [q0, q1)
-    if (q0 >= q1 || p0 >= p1) return 0;
-    return p1 - p0 == 1 ? launch_trailing_update(bulk, packed, n_pad, p0, q0, q1, 1) : launch_trailing_range(bulk, packed, n_pad, p0, p1, q0, q1, 1);
-  };
-  int64_t far_from = 0;                                       // panels [0, far_from) have been applied to everything behind them
-  for (int64_t p = 0; p + 1 < P; ++p) {
-    GPRC_TRY(stream_after(ctx, bulk, side));                  // panel p is factored
-    GPRC_TRY(update(far_from, p + 1, p + 1, p + 2));          // panel p + 1 first ...
-    GPRC_TRY(stream_after(ctx, side, bulk));
-    GPRC_TRY(launch_panel_fused(side, packed, n_pad, p + 1, winv, info_dev, sync_side));   // ... its chain on the side stream
-    if (p + 1 - far_from >= batch || p + 2 >= P) {            // ... beside the far update
-      GPRC_TRY(update(far_from, p + 1, p + 2, P));
-      far_from = p + 1;
-    }
-  }
-  GPRC_TRY(stream_after(ctx, s, side));
-  if (bulk != s) GPRC_TRY(stream_after(ctx, s, bulk));
-  return 0;
-}
-
 // Set when a factorisation under the factor service ended in a device-side wait timeout: the persistent launch and the caller's
 // kernels did not run concurrently (a tool that serialises dispatches, e.g. rocprofv3 --pmc).  From then on this process factors with
 // one fused launch per panel (what GPRC_SERVICE=0 selects).
@@ -451,15 +373,11 @@ int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv,
   int64_t want = want_for(n_pad);
   if (mode && std::strcmp(mode, "right") == 0) want = INT64_MAX;
   else if (mode && std::atoll(mode) > 0) want = std::atoll(mode);
-  // GPRC_LOOKAHEAD1=1: the look-ahead-on-streams sweep (superseded); GPRC_PANEL=steps: the launch-per-stage panel kernels;
-  // GPRC_SERVICE=0: one fused launch per panel inside the groups instead of the factor service
-  static const int la_env = [] { const char* e = std::getenv("GPRC_LOOKAHEAD1"); return e ? std::atoi(e) : -1; }();
+  // GPRC_PANEL=steps: the launch-per-stage panel kernels; GPRC_SERVICE=0: one fused launch per panel inside the groups instead of
+  // the factor service.  (A look-ahead sweep on two streams, with and without CU masks, was measured in round 2 and removed in
+  // favour of the service: DESIGN.md section 3, profiles/r02_experiments.txt.)
   static const bool panel_steps = [] { const char* e = std::getenv("GPRC_PANEL"); return e && std::strcmp(e, "steps") == 0; }();
   static const int sv_env = [] { const char* e = std::getenv("GPRC_SERVICE"); return e ? std::atoi(e) : -1; }();
-  if (!mode && !panel_steps && P >= 2 && la_env == 1) {
-    GPRC_TRY(factor_all_lookahead(ctx, packed, n_pad, winv, info_dev));
-    return inv ? launch_inv512(s, packed, n_pad, winv, inv, 0, P) : 0;
-  }
   const bool service = !panel_steps && sv_env != 0 && P >= 2 && !g_service_off.load();
   DevMem sync;   // flags of every panel + the counters; goes back to the pool when every launch below has been ordered behind it
   void* trace = nullptr;
@@ -841,7 +759,6 @@ int gprc_ctx_destroy(gprc_ctx* ctx) {
   if (ctx->sync_dev) (void)hipFree(ctx->sync_dev);
   if (ctx->svc_trace) (void)hipFree(ctx->svc_trace);
   if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
-  if (ctx->upd_stream) { (void)hipStreamSynchronize(ctx->upd_stream); (void)hipStreamDestroy(ctx->upd_stream); }
   for (hipEvent_t ev : ctx->ev_pool)
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -2,13 +2,15 @@
 //
 // Replaces L <- t(chol(K + noise * diag(n)))  (reference R/GPRclass.R:142, LAPACK dpotrf) and, through
 // the same GEMM tile, v <- solve(L, K_star) (R/GPRclass.R:162, which the reference runs as a general
-// pivoted dgesv).  Three kernels:
-//   potf2_inv_kernel  one workgroup factors a 128x128 diagonal block entirely in LDS and also forms
+// pivoted dgesv).  The pieces:
+//   potf2_blocked_body  one workgroup factors a 128x128 diagonal block entirely in LDS and also forms
 //                     its inverse (so every panel / right-hand-side solve below is a GEMM);
 //   gemm tile core    128x128 output tile per 256-thread workgroup, 4 waves x (64x64) of
 //                     v_mfma_f64_16x16x4_f64, A/B strips staged through double-buffered LDS;
 //   wrappers          panel solve (X := X * Winv^T, in place), in-panel / general C -= A*B^T, and the
-//                     trailing update over the packed block-column layout (lower tiles only).
+//                     trailing update over the packed block-column layout (lower tiles only);
+//   panel_fused_kernel / panel_service_kernel   a whole panel's dependent chain in one launch / every panel's in one
+//                     persistent launch (the factor service), with the caller's-stream kernels that go with it.
 // The trailing update is the dominant kernel of the whole path: n^3/3 of the fit and n^2 n* of the
 // predict go through gemm_tile_128().
 #include <algorithm>
@@ -26,90 +28,6 @@ namespace {
 // Diagonal block: Cholesky + inverse of a 128 x 128 block in one sweep by one workgroup.
 // ------------------------------------------------------------------------------------------------
 constexpr int PB = 128;
-
-// Register-resident formulation.  Thread (i = t & 127, ty = t >> 7) owns the 16 logical elements
-// (i, c = ty + 8k), k = 0..15, in registers.  Element (i, c), c <= i, holds the Cholesky working entry
-// A[i][c] until step c, where it becomes L[i][c] (stored to global at once) and the register is re-used for
-// the UNSCALED inverse entry Y[i][c] = l_ii * (L^-1)[i][c], which the same rank-1 sweep keeps eliminating:
-//     step j, row i > j:   c > j : A[i][c] -= L[i][j] * L[c][j]
-//                          c = j : L[i][j] = A[i][j] / l_jj  -> out;  Y[i][j] = -L[i][j] / l_jj
-//                          c < j : Y[i][c] -= L[i][j] * X[j][c],   X[j][c] = Y[j][c] / l_jj
-// With m_c = line[c] / l_jj (line = the published pivot column below j and pivot row of Y left of j) both
-// updates are the SAME fma, so the sweep is branch-free: rows i <= j use a zero multiplier, dead elements
-// (c > i) are updated harmlessly and never read, and row scaling is deferred to the final store.
-// Only the pivot column (owners: ty == j % 8) and row j of Y (owners: i == j) cross threads, through a
-// double-buffered LDS line: ONE barrier per column.  Scaling multiplies by 1/l_jj as LAPACK dpotf2 does.
-// TY = number of column groups: TY * 128 threads, E = 128 / TY elements per thread (c = ty + TY * k).
-template <int TY>
-__global__ __launch_bounds__(TY * 128) void potf2_inv_kernel(double* A, int64_t lda, double* winv, int* info, int col0) {
-  constexpr int E = PB / TY;
-  __shared__ double pub[2][PB + 2];  // [PB] = l_jj, [PB+1] = 1/l_jj, computed once by the pivot's owner
-  const int t = threadIdx.x;
-  const int i = t & 127, ty = t >> 7;
-  const int wave_last_row = (t & 64) + 63;   // rows of this wave: (t & 64) .. +63
-  double reg[E];
-  double my_rinv = 1.0;
-#pragma unroll
-  for (int k = 0; k < E; ++k) {
-    const int c = ty + TY * k;
-    reg[k] = (c <= i) ? A[i + (int64_t)c * lda] : 0.0;
-  }
-#pragma unroll
-  for (int kb = 0; kb < E; ++kb) {     // compile-time register index of the pivot column: reg[kb]
-#pragma unroll 1
-    for (int jj = 0; jj < TY; ++jj) {
-      const int j = kb * TY + jj;
-      double* line = pub[j & 1];
-      // publish: pivot column A[.][j] (rows >= j) by its owners, row j of Y (cols < j) by row j
-      if (ty == jj && i >= j) line[i] = reg[kb];
-      if (i == j) {
-        if (ty == jj) {
-          const double l = sqrt(reg[kb]);
-          line[PB] = l;
-          line[PB + 1] = 1.0 / l;
-        }
-#pragma unroll
-        for (int k = 0; k < E; ++k) {
-          const int c = ty + TY * k;
-          if (c < j) line[c] = reg[k];
-        }
-      }
-      __syncthreads();
-      if (wave_last_row < j) continue;   // wave-uniform: every row of this wave is final
-      const double d = line[j];
-      if (!(d > 0.0) && t == 0) atomicCAS(info, 0, col0 + j + 1);  // LAPACK info: first non-PD leading minor
-      const double ljj = line[PB];
-      const double rinv = line[PB + 1];
-      const bool below = i > j;
-      const double lij = below ? line[i] * rinv : 0.0;
-      const double mult = -lij * rinv;   // -(L[i][j] / l_jj): one fma per element against the UNSCALED line
-      if (wave_last_row >= 64) {
-        double lv[E];
-#pragma unroll
-        for (int k = 0; k < E; ++k) lv[k] = line[ty + TY * k];
-#pragma unroll
-        for (int k = 0; k < E; ++k) reg[k] = fma(mult, lv[k], reg[k]);
-      } else {                           // rows 0..63: columns c > 63 are all above the diagonal
-        double lv[E / 2];
-#pragma unroll
-        for (int k = 0; k < E / 2; ++k) lv[k] = line[ty + TY * k];
-#pragma unroll
-        for (int k = 0; k < E / 2; ++k) reg[k] = fma(mult, lv[k], reg[k]);
-      }
-      if (ty == jj) {                    // the pivot column itself: final L[i][j], first inverse entry
-        if (below) { A[i + (int64_t)j * lda] = lij; reg[kb] = mult; }
-        else if (i == j) { A[j + (int64_t)j * lda] = ljj; reg[kb] = 1.0; }
-      }
-      if (i == j) my_rinv = rinv;
-    }
-  }
-  // Winv = L^-1 = diag(1/l_ii) * Y, dense 128 x 128 column-major, zero above the diagonal
-#pragma unroll
-  for (int k = 0; k < E; ++k) {
-    const int c = ty + TY * k;
-    winv[i + c * PB] = (c <= i) ? reg[k] * my_rinv : 0.0;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Blocked diagonal-block kernel (default): the same factor + inverse, 16 columns at a time.
@@ -1329,21 +1247,15 @@ __global__ __launch_bounds__(256, 2) void trailing_service_kernel(double* packed
 
 int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* info_dev, int col0) {
   ProfScope ps(s, PK_POTF2, 128.0 * 128 * 128 / 3 * 2, 8.0 * 3 * 128 * 128);
-  static const bool scalar = std::getenv("GPRC_POTF2_SCALAR") != nullptr;  // the unblocked register-resident kernel
-  if (scalar) {
-    // 8 column groups x 128 rows = 1024 threads; 4 and 2 groups (fatter threads) measured 6x and 9x slower
-    hipLaunchKernelGGL(potf2_inv_kernel<8>, dim3(1), dim3(1024), 0, s, A, lda, winv, info_dev, col0);
-  } else {
-    static bool attr_set[MAX_DEVICES] = {};  // the attribute is per device: one process may hold contexts on several
-    const size_t smem = PB_SMEM_DOUBLES * sizeof(double);
-    int dev = 0;
-    GPRC_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= MAX_DEVICES || !attr_set[dev]) {
-      GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_blocked_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      if (dev >= 0 && dev < MAX_DEVICES) attr_set[dev] = true;
-    }
-    hipLaunchKernelGGL(potf2_inv_blocked_kernel, dim3(1), dim3(1024), smem, s, A, lda, winv, info_dev, col0);
+  static bool attr_set[MAX_DEVICES] = {};  // the attribute is per device: one process may hold contexts on several
+  const size_t smem = PB_SMEM_DOUBLES * sizeof(double);
+  int dev = 0;
+  GPRC_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEVICES || !attr_set[dev]) {
+    GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_blocked_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (dev >= 0 && dev < MAX_DEVICES) attr_set[dev] = true;
   }
+  hipLaunchKernelGGL(potf2_inv_blocked_kernel, dim3(1), dim3(1024), smem, s, A, lda, winv, info_dev, col0);
   GPRC_LAUNCH_CHECK();
   return 0;
 }
@@ -1563,7 +1475,7 @@ int launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64
   if (tiles > 0x7fffffff) { set_error("gemm_nt: too many tiles"); return GPRC_ERR_ARG; }
   const double useful = lower ? 0.5 : 1.0;  // algorithmic: the lower triangle only
   ProfScope ps(s, kind, 2.0 * M * N * K * useful, 8.0 * (2.0 * M * N * useful + (M + N) * (double)K));
-  static const int pg = std::getenv("GPRC_PERSIST") ? std::atoi(std::getenv("GPRC_PERSIST")) : 0;  // >0: persistent grid of that many workgroups (measured slower: DESIGN.md 6)
+  constexpr int pg = 0;   // (a persistent grid of N workgroups striding over the tile list measured 4 % slower: DESIGN.md 3)
   const dim3 grid((unsigned)((pg > 0 && tiles > pg) ? pg : tiles)), block(256);
   const size_t smem = G_SMEM_DOUBLES * sizeof(double);
   const int tm = (int)(M / 128), tn = (int)(N / 128);
@@ -1594,7 +1506,7 @@ int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t
   }
   ProfScope ps(s, PK_TRAILING, fl, by);
 
-  static const int pg = std::getenv("GPRC_PERSIST") ? std::atoi(std::getenv("GPRC_PERSIST")) : 0;
+  constexpr int pg = 0;
   const unsigned grid = (unsigned)((pg > 0 && tiles > pg) ? pg : tiles);
   hipLaunchKernelGGL(trailing_kernel, dim3(grid), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)p,
                      (int)q_begin, (int)q_stride, (int)nt, (int)tiles);

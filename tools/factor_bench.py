@@ -1,7 +1,7 @@
 """gprc_dev_factor_all alone (packed sqexp kernel matrix resident, refilled by a device copy each repetition) under the schedule the
 environment selects: milliseconds and TFLOP/s (n^3/3) per size.
     python tools/factor_bench.py 8192 16384 24576            # default schedule
-    GPRC_SERVICE=0 GPRC_LOOKAHEAD1=0 python tools/factor_bench.py ...   # grouped left-looking, one fused launch per panel"""
+    GPRC_SERVICE=0 python tools/factor_bench.py ...   # grouped left-looking, one fused launch per panel"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

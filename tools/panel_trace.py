@@ -1,9 +1,10 @@
 """Where the time of one fused panel launch goes: stage stamps of the factor role (the critical chain) of panel GPRC_PANEL_TRACE
 (default 0) during ONE fit at n (default 8192), printed in microseconds.
-    GPRC_PANEL_TRACE=0 GPRC_LOOKAHEAD1=0 python tools/panel_trace.py [n]"""
+    GPRC_PANEL_TRACE=0 GPRC_SERVICE=0 python tools/panel_trace.py [n]     (the fused launch per panel, not the factor service)"""
 import ctypes as C, os, sys
 os.environ.setdefault("GPRC_PANEL_TRACE", "0")
-os.environ.setdefault("GPRC_LOOKAHEAD1", "0")
+os.environ.setdefault("GPRC_SERVICE", "0")
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import gprc_amd

@@ -1,8 +1,8 @@
 """Where the 46 us of one diagonal-block factorisation (potf2_blocked_body<8>, second block of panel 0) go: stamps in microseconds.
-    GPRC_POTF2_TRACE=1 GPRC_PANEL_TRACE=0 GPRC_SERVICE=0 GPRC_LOOKAHEAD1=0 python tools/potf2_trace.py [n]"""
+    GPRC_POTF2_TRACE=1 GPRC_PANEL_TRACE=0 GPRC_SERVICE=0 python tools/potf2_trace.py [n]"""
 import ctypes as C, os, sys
 os.environ.setdefault("GPRC_POTF2_TRACE", "1"); os.environ.setdefault("GPRC_PANEL_TRACE", "0")
-os.environ.setdefault("GPRC_SERVICE", "0"); os.environ.setdefault("GPRC_LOOKAHEAD1", "0")
+os.environ.setdefault("GPRC_SERVICE", "0")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import gprc_amd
