@@ -17,8 +17,11 @@ is the same at every N (strong scaling).  `--workload c2|c3` select the other si
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant kernel, HIP
 events recorded inside the native library on the launching stream), `parity_timed_config_normwise_err` (the
-outputs of the LAST TIMED step against an independent small-batch predict and the K alpha = y - noise alpha
-identity; the run FAILS above 1e-9) and, at N = 1, `cpu_baseline` (three CPU lines on a bounded sample).
+outputs of the LAST TIMED step against an independent small-batch predict, the K alpha = y - noise alpha
+identity and -- mean AND variance -- a vendor-LAPACK fp64 reference that shares nothing with the library; the run
+FAILS above 1e-10) and, at N = 1, `cpu_baseline` (three CPU lines on a bounded sample) and `abi_host_path` (the
+drop-in boundary as R's `.Call` would use it: gprc_gpr_fit_retry + gprc_gpr_predict with HOST pointers on the
+timed workload, one cold call -- first-call device allocations included -- and one warm call).
 
 GPRC_BENCH_BACKEND=gloo: ranks exchange through gloo and share cuda:(LOCAL_RANK mod device count) -- how
 `pytest -m gpu` rehearses `--gpus 2` on a one-GPU box.  Default backend: nccl (= RCCL over xGMI).
@@ -39,7 +42,8 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X spec, fp64 matrix (dense); measured 77.5 by tools/microbench/mfma_f64.hip
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-PARITY_FAIL = 1e-9             # the run fails when the timed outputs are further than this from the independent values
+PARITY_FAIL = 1e-10            # the north star's tolerance: the run fails when the timed outputs are further than this from
+                               # the independent values (observed: 0.0 bitwise / 2e-13 / 1e-13)
 
 WORKLOADS = {
     # name: (n, d, kernel name, params, n_star or None -> reference grid rule)
@@ -222,6 +226,58 @@ def timed_config_parity(eng, ops, bufs, X, y, Xs, lo, hi, mean, var, noise=0.1, 
     return out
 
 
+def vendor_parity(kname, X, y, Xs, lo, hi, mean, var, alpha, device, noise=0.1, rows=256):
+    """The leg that is independent of the library, for mean AND variance: `rows` strided rows of this rank's slice of the
+    LAST TIMED step's outputs against the predict step rebuilt from vendor LAPACK / BLAS on the same GPU
+    (tools/vendor_reference.py: rocSOLVER potrf, rocBLAS trsm / gemm through torch.linalg; K in slabs with direct
+    sum (x - y)^2).  Only the workloads' own kernels (sqrexp l = 1, rationalquadratic l = 1 alpha = 1.5)."""
+    from tools.vendor_reference import lapack_reference_subset
+    m = hi - lo
+    if m <= 0 or kname not in ("sqrexp", "rationalquadratic"):
+        return None
+    idx = np.unique(np.linspace(0, m - 1, min(rows, m)).astype(np.int64))
+    t0 = time.perf_counter()
+    a_ref, m_ref, v_ref = lapack_reference_subset(kname, X.T, y, np.ascontiguousarray(Xs[lo:hi][idx].T), noise, device=device)
+    nrm = lambda got, ref: float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300))
+    return {"rows": int(idx.size), "alpha_err": nrm(alpha, a_ref), "mean_err": nrm(mean[idx], m_ref), "var_err": nrm(var[idx], v_ref),
+            "seconds": round(time.perf_counter() - t0, 2)}
+
+
+def abi_host_path(device, kname, params, X, y, Xs, resident_ms):
+    """The drop-in boundary as the reference's host would drive it (`.Call` hands REAL(x) pointers):
+    gprc_gpr_fit_retry + gprc_gpr_predict with HOST arrays on the timed workload, on a fresh context.  Cold = the first
+    call on that context (device allocations of the model -- 17 GB at C4 -- and of the predict chunk, H2D of X, y, X*,
+    D2H of alpha / mean / var); warm = the same call again (blocks come back from the context's free-list)."""
+    import ctypes as C
+    from gprc_amd import _native as nat
+    L = nat.lib()
+    ctx = nat.Context(device, None)
+    Xc, yc, Xsc = np.ascontiguousarray(X), np.ascontiguousarray(y), np.ascontiguousarray(Xs)   # row i = point i == d x n column-major
+    n, d = Xc.shape
+    ns = Xsc.shape[0]
+    _, pp, npar = nat.params_array(params)
+    mean, var = np.empty(ns), np.empty(ns)
+    rec = {}
+    try:
+        for name in ("cold", "warm"):
+            model, nu, att = C.c_void_p(), C.c_double(), C.c_int()
+            t0 = time.perf_counter()
+            nat.check(L.gprc_gpr_fit_retry(ctx.handle, KERNEL_IDS[kname], pp, npar, Xc.ctypes.data, d, n, yc.ctypes.data, 0.1, C.byref(model),
+                                           C.byref(nu), C.byref(att)))
+            t1 = time.perf_counter()
+            nat.check(L.gprc_gpr_predict(model, Xsc.ctypes.data, ns, 1, mean.ctypes.data, var.ctypes.data))
+            t2 = time.perf_counter()
+            L.gprc_model_free(model)
+            rec[name] = {"fit_ms": round((t1 - t0) * 1e3, 2), "predict_ms": round((t2 - t1) * 1e3, 2), "step_ms": round((t2 - t0) * 1e3, 2)}
+    finally:
+        ctx.close()
+    rec["resident_step_ms"] = round(resident_ms, 2)
+    rec["warm_minus_resident_ms"] = round(rec["warm"]["step_ms"] - resident_ms, 2)
+    rec["cold_minus_resident_ms"] = round(rec["cold"]["step_ms"] - resident_ms, 2)
+    rec["what"] = "gprc_gpr_fit_retry + gprc_gpr_predict(pointwise) with host pointers, fresh context; cold = first call (allocations included)"
+    return rec, mean, var
+
+
 # ---- launching -------------------------------------------------------------------------------------------------------
 def free_port():
     s = socket.socket()
@@ -261,6 +317,8 @@ def main():
     ap.add_argument("--nstar", type=int, default=0, help="override n* (random test points instead of the grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
+    ap.add_argument("--no-abi-host-path", action="store_true", help="skip the host-pointer (.Call-shaped) cold/warm timing at N = 1")
+    ap.add_argument("--no-vendor-parity", action="store_true", help="skip the vendor-LAPACK leg of the timed-output parity check")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
         raise SystemExit("bench.py: --gpus >= 1, --steps >= 1, --warmup >= 0")
@@ -386,9 +444,13 @@ def main():
     var = ops.to_host(bufs["var"])[: hi - lo]
     sane = bool(np.isfinite(mean).all() and np.isfinite(var).all() and (var > -1e-8).all())
     tp = timed_config_parity(eng, ops, bufs, X, y, Xs, lo, hi, mean, var)
-    par_err, id_err, bad = all_max([tp["normwise_err"], tp["identity_err"],
-                                    0.0 if (sane and tp["var_bounds_ok"] and tp["bitwise_equal"]) else 1.0])
-    parity_ok = bool(par_err <= PARITY_FAIL and id_err <= PARITY_FAIL and bad == 0.0)
+    vp = None
+    if rank == 0 and not args.no_vendor_parity:   # rank 0's slice against vendor LAPACK: independent of the library, mean AND variance
+        vp = vendor_parity(kname, X, y, Xs, lo, hi, mean, var, ops.to_host(eng.alpha)[:n], device)
+    vend_err = max(vp["alpha_err"], vp["mean_err"], vp["var_err"]) if vp else 0.0
+    par_err, id_err, bad, vend_err = all_max([tp["normwise_err"], tp["identity_err"],
+                                              0.0 if (sane and tp["var_bounds_ok"] and tp["bitwise_equal"]) else 1.0, vend_err])
+    parity_ok = bool(par_err <= PARITY_FAIL and id_err <= PARITY_FAIL and vend_err <= PARITY_FAIL and bad == 0.0)
 
     phases = all_gather_rows([sum(a.elapsed_time(b) for a, b, _ in marks) / len(marks), sum(b.elapsed_time(c) for _, b, c in marks) / len(marks)])
 
@@ -449,9 +511,17 @@ def main():
             "parity_gate_normwise_err": gate_err,
             "parity_timed_config_normwise_err": par_err,
             "parity_timed_config": {"rows_rank0": tp["rows"], "bitwise_equal_to_small_batch": bad == 0.0 or tp["bitwise_equal"],
-                                    "identity_K_alpha_normwise_err": id_err, "fail_above": PARITY_FAIL, "ok": parity_ok},
+                                    "identity_K_alpha_normwise_err": id_err, "vendor_lapack": vp, "fail_above": PARITY_FAIL, "ok": parity_ok},
             "outputs_sane": sane,
         }
+        if world == 1 and not args.no_abi_host_path and parity_ok:
+            # the resident engine's buffers go first: the cold call must find the device as R's first call would
+            ops.close()
+            del eng, bufs
+            torch.cuda.empty_cache()
+            rec, hmean, hvar = abi_host_path(device, kname, params, X, y, Xs, ms)
+            rec["bitwise_equal_to_resident_path"] = bool(np.array_equal(hmean[lo:hi], mean) and np.array_equal(hvar[lo:hi], var))
+            out["abi_host_path"] = rec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kname, params, d)
         if parity_ok:
@@ -459,7 +529,8 @@ def main():
         else:   # a fast step with wrong outputs is not a measurement: no JSON line on stdout
             print("bench.py: PARITY FAILURE of the timed configuration: " + json.dumps(out["parity_timed_config"]) +
                   f" normwise_err={par_err}", file=sys.stderr, flush=True)
-    ops.close()
+    if not ops.closed:
+        ops.close()
     if use_dist:
         torch.distributed.destroy_process_group()
     if not parity_ok:

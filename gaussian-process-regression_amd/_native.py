@@ -102,6 +102,9 @@ PROTOTYPES = {
     "gprc_mgpu_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(_vp)]),
     "gprc_mgpu_destroy": (C.c_int, [_vp]),
     "gprc_mgpu_ranks": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "gprc_mgpu_calibrate": (C.c_int, [_vp, _i64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "gprc_mgpu_exchange_mode": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "gprc_mgpu_stats": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int]),
     "gprc_mgpu_gpr_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, C.c_double, C.POINTER(_vp)]),
     "gprc_mgpu_gpr_fit_retry": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _vp, C.c_double, C.POINTER(_vp),
                                           C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -351,11 +351,16 @@ class HipOps:
         finally:
             self.L.gprc_model_free(model)
 
+    closed = False
+
     def close(self):
+        if self.closed:
+            return
         self.synchronize()
         self.ctx_main.close()
         self.ctx_side.close()
         self.ctx_aux.close()
+        self.closed = True
 
 
 def owned_after(p: int, rank: int, world: int) -> int:

@@ -44,7 +44,8 @@ class _ReadOnly:
 class GPR:
     """GPR$new(X, y, noise = 0, k, cov_names)  --  R/GPRclass.R:127-128."""
 
-    def __init__(self, X, y, noise=0, k=None, cov_names=None, *, ctx=None, devices=None, rccl=False):
+    def __init__(self, X, y, noise=0, k=None, cov_names=None, *, ctx=None, devices=None, rccl=False, exchange="broadcast",
+                 lookahead=True):
         if k is None:
             # the reference default: k = fit(X, y, noise, cov_names)$func (R/GPRclass.R:127); all six kernels of the
             # default list are covered (Brent for the one-parameter kernels and the polynomial degree loop, vmmin/BFGS
@@ -72,7 +73,9 @@ class GPR:
         if devices is not None and (len(devices) > 1 or rccl):
             # the reference's GPR$new over several GPUs from this ONE process (gprc_mgpu_*; the R side: options(gprc.devices = ...)).
             # `devices` may list a device several times: virtual ranks sharing a GPU (peer copies only).
-            self._mgpu = _mgpu_for(tuple(int(v) for v in devices), bool(rccl))
+            # exchange: the form of the one exchange step -- "broadcast" (rooted), "scatter_allgather" (large-message form) or
+            # "auto" (both timed at creation, the faster kept); lookahead=False: factor panel p+1 only after update p.
+            self._mgpu = _mgpu_for(tuple(int(v) for v in devices), bool(rccl), exchange, bool(lookahead))
             self._mmodel = C.c_void_p()
             rc = nat.lib().gprc_mgpu_gpr_fit_retry(self._mgpu, k.gprc_kernel[0], pp, npar, Xm.ctypes.data, d, n, y.ctypes.data, float(noise),
                                                    C.byref(self._mmodel), C.byref(noise_used), C.byref(attempts))
@@ -187,16 +190,40 @@ class GPR:
 _mgpu_cache = {}
 
 
-def _mgpu_for(devices, rccl):
-    """One gprc_mgpu per (devices, rccl) for the life of the process: creating streams / RCCL communicators is not free."""
-    key = (devices, rccl)
+MGPU_RCCL, MGPU_NO_LOOKAHEAD, MGPU_SCATTER_ALLGATHER, MGPU_AUTO_EXCHANGE = 1, 2, 4, 8   # include/gprc_native.h
+
+
+def _mgpu_for(devices, rccl, exchange="broadcast", lookahead=True):
+    """One gprc_mgpu per (devices, flags) for the life of the process: creating streams / RCCL communicators is not free, and
+    fitted models keep handles into it."""
+    try:
+        ex = {"broadcast": 0, "scatter_allgather": MGPU_SCATTER_ALLGATHER, "auto": MGPU_AUTO_EXCHANGE}[exchange]
+    except KeyError:
+        raise ValueError('exchange must be "broadcast", "scatter_allgather" or "auto"') from None
+    flags = (MGPU_RCCL if rccl else 0) | (0 if lookahead else MGPU_NO_LOOKAHEAD) | ex
+    key = (devices, flags)
     h = _mgpu_cache.get(key)
     if h is None:
         h = C.c_void_p()
         arr = (C.c_int * len(devices))(*devices)
-        nat.check(nat.lib().gprc_mgpu_create(arr, len(devices), 1 if rccl else 0, C.byref(h)))
+        nat.check(nat.lib().gprc_mgpu_create(arr, len(devices), flags, C.byref(h)))
         _mgpu_cache[key] = h
     return h
+
+
+def mgpu_stats(handle):
+    """gprc_mgpu_stats as a dict: what the last fit / predict on this gprc_mgpu did (a schedule-rehearsal record)."""
+    g = C.c_int()
+    nat.check(nat.lib().gprc_mgpu_ranks(handle, C.byref(g)))
+    out = (C.c_double * (10 + 3 * g.value))()
+    nat.check(nat.lib().gprc_mgpu_stats(handle, out, len(out)))
+    names = ["ranks", "panels", "exchange_mode", "exchange_ops", "bytes_in_per_rank", "event_pairs", "far_passes", "lookahead_updates",
+             "fit_ms", "predict_ms"]
+    rec = {k: (float(out[i]) if k.endswith("_ms") else int(out[i])) for i, k in enumerate(names)}
+    rec["exchange"] = ["copies/broadcast", "rccl/broadcast", "copies/scatter_allgather", "rccl/scatter_allgather"][rec["exchange_mode"]]
+    rec["per_rank"] = [{"rank": r, "fill_sweep_ms": round(out[10 + 3 * r], 3), "alpha_logp_ms": round(out[11 + 3 * r], 3),
+                        "predict_ms": round(out[12 + 3 * r], 3)} for r in range(g.value)]
+    return rec
 
 
 def _fitted(X, y, noise, kernel, ctx=None):

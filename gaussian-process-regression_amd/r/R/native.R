@@ -42,10 +42,16 @@ covariance_matrix <- function(A, B, covariance_function) {
 
 # Multi-GPU: options(gprc.devices = 0:7) makes GPR$new / $predict(pointwise_var = TRUE) run the block-cyclic sweep over
 # those GPUs from this one R process (gprc_mgpu_* of include/gprc_native.h: R cannot be forked per GPU);
-# options(gprc.rccl = TRUE) selects the RCCL broadcast for the panel exchange (default: peer copies).
+# options(gprc.rccl = TRUE) selects the RCCL broadcast for the panel exchange (default: peer copies);
+# options(gprc.exchange = "scatter_allgather" | "auto") the large-message form of that step (GPRC_MGPU_SCATTER_ALLGATHER /
+# GPRC_MGPU_AUTO_EXCHANGE: timed against the rooted broadcast when the ranks are created, the faster kept).
 .gprc_devices <- function() {
   dv <- getOption("gprc.devices", NULL)
   if (is.null(dv) || length(dv) < 2L) NULL else as.integer(dv)
+}
+.gprc_mgpu_flags <- function() {
+  ex <- match.arg(getOption("gprc.exchange", "broadcast"), c("broadcast", "scatter_allgather", "auto"))
+  (if (isTRUE(getOption("gprc.rccl", FALSE))) 1L else 0L) + c(broadcast = 0L, scatter_allgather = 4L, auto = 8L)[[ex]]
 }
 
 # body of GPR$initialize after the input checks (R/GPRclass.R:134-153), native branch
@@ -54,7 +60,7 @@ covariance_matrix <- function(A, B, covariance_function) {
   storage.mode(X) <- "double"
   dv <- .gprc_devices()
   res <- if (is.null(dv)) .Call(gprc_R_gpr_fit, tag$id, tag$params, X, as.double(y), as.double(noise))
-         else .Call(gprc_R_mgpu_gpr_fit, dv, if (isTRUE(getOption("gprc.rccl", FALSE))) 1L else 0L, tag$id, tag$params, X,
+         else .Call(gprc_R_mgpu_gpr_fit, dv, .gprc_mgpu_flags(), tag$id, tag$params, X,
                     as.double(y), as.double(noise))
   private$.multi <- !is.null(dv)
   if (res[[3]] > 1L) warning(sprintf("Noise got changed to %s to avoid errors in cholesky decomposition", res[[2]]))

@@ -113,24 +113,32 @@ SEXP gprc_R_gpr_predict(SEXP handle, SEXP X_star, SEXP pointwise) {
 }
 
 /* ---- multi-GPU from R's one process: options(gprc.devices = c(0, 1, ..., 7)) selects it (native.R) ------------------
- * One gprc_mgpu per distinct (devices, flags) request, kept for the session: creating the streams / RCCL communicators
- * is not free.  The model handle is a gprc_mgpu_model behind its own external-pointer class. */
-static gprc_mgpu* g_mgpu = NULL;
-static int g_mgpu_devs[64], g_mgpu_n = 0, g_mgpu_flags = -1;
+ * One gprc_mgpu per distinct (devices, flags) request, ALL kept until the package is unloaded: creating the streams / RCCL
+ * communicators is not free, and GPR objects fitted earlier hold gprc_mgpu_model handles into theirs -- destroying a
+ * gprc_mgpu when options(gprc.devices / gprc.rccl) change would leave those objects' $predict and their finalizers on freed
+ * ranks (the library additionally refuses a model whose gprc_mgpu is gone: include/gprc_native.h, "Lifetime").  The model
+ * handle is a gprc_mgpu_model behind its own external-pointer class. */
+#define GPRC_MGPU_SLOTS 16
+static struct { gprc_mgpu* mg; int devs[64], n, flags; } g_mgpus[GPRC_MGPU_SLOTS];
+static int g_mgpu_count = 0;
 
 static gprc_mgpu* mgpu_for(SEXP devices, SEXP flags) {
   const int n = LENGTH(devices), fl = Rf_asInteger(flags);
   if (n < 1 || n > 64) Rf_error("gprc: 1..64 devices");
-  int same = g_mgpu != NULL && n == g_mgpu_n && fl == g_mgpu_flags;
-  for (int i = 0; same && i < n; ++i) same = INTEGER(devices)[i] == g_mgpu_devs[i];
-  if (!same) {
-    if (g_mgpu) { gprc_mgpu_destroy(g_mgpu); g_mgpu = NULL; }
-    if (gprc_mgpu_create(INTEGER(devices), n, fl, &g_mgpu) != 0) Rf_error("gprc: %s", gprc_last_error());
-    for (int i = 0; i < n; ++i) g_mgpu_devs[i] = INTEGER(devices)[i];
-    g_mgpu_n = n;
-    g_mgpu_flags = fl;
+  for (int k = 0; k < g_mgpu_count; ++k) {
+    int same = n == g_mgpus[k].n && fl == g_mgpus[k].flags;
+    for (int i = 0; same && i < n; ++i) same = INTEGER(devices)[i] == g_mgpus[k].devs[i];
+    if (same) return g_mgpus[k].mg;
   }
-  return g_mgpu;
+  if (g_mgpu_count == GPRC_MGPU_SLOTS) Rf_error("gprc: more than %d distinct (gprc.devices, flags) settings in one session", GPRC_MGPU_SLOTS);
+  gprc_mgpu* mg = NULL;
+  if (gprc_mgpu_create(INTEGER(devices), n, fl, &mg) != 0) Rf_error("gprc: %s", gprc_last_error());
+  g_mgpus[g_mgpu_count].mg = mg;
+  for (int i = 0; i < n; ++i) g_mgpus[g_mgpu_count].devs[i] = INTEGER(devices)[i];
+  g_mgpus[g_mgpu_count].n = n;
+  g_mgpus[g_mgpu_count].flags = fl;
+  ++g_mgpu_count;
+  return mg;
 }
 
 static void mgpu_model_finalizer(SEXP ptr) {
@@ -330,6 +338,9 @@ void R_init_gprc(DllInfo* dll) {
 
 void R_unload_gprc(DllInfo* dll) {
   (void)dll;
-  if (g_mgpu) { gprc_mgpu_destroy(g_mgpu); g_mgpu = NULL; }
+  /* Finalizers of GPR objects may still be pending when the package is unloaded: the library keeps registries of live contexts /
+   * gprc_mgpu objects, so a model freed afterwards hands its memory back without touching what is destroyed here. */
+  for (int k = 0; k < g_mgpu_count; ++k) gprc_mgpu_destroy(g_mgpus[k].mg);
+  g_mgpu_count = 0;
   if (g_ctx) { gprc_ctx_destroy(g_ctx); g_ctx = NULL; }
 }

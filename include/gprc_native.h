@@ -258,18 +258,37 @@ GPRC_API int gprc_dev_solve_rows(gprc_ctx* ctx, const double* packed, const doub
  * predict are sliced over the ranks with no exchange.  Replaces GPR$initialize / GPR$predict (R/GPRclass.R:127-170)
  * exactly as gprc_gpr_fit / gprc_gpr_predict do, with bit-identical results.
  *   devices  n_ranks device indices.  A device may be listed SEVERAL times: "virtual ranks" that share a GPU and
- *            exchange panels by device-to-device copies -- how a one-GPU box exercises the G = 2, 3 sweeps.
+ *            exchange panels by device-to-device copies -- how a one-GPU box exercises the G = 2, 3, 8 sweeps.
  *   flags    GPRC_MGPU_RCCL: the exchange is ncclBroadcast over xGMI (single-process ncclCommInitAll + group calls;
  *            distinct devices only; librccl.so.1 is resolved at run time).  0: peer copies (hipMemcpyPeerAsync).
  *            GPRC_MGPU_NO_LOOKAHEAD: factor panel p+1 only after the whole trailing update of panel p.
  * All data pointers of these calls are HOST memory (REAL(x) of the `.Call` case). */
 #define GPRC_MGPU_RCCL 1
 #define GPRC_MGPU_NO_LOOKAHEAD 2
+/*            GPRC_MGPU_SCATTER_ALLGATHER: the large-message form of the exchange step (last row).  xGMI is
+ *            point-to-point: a rooted broadcast leaves the owner G - 1 times at one link's rate each; here the owner hands
+ *            piece r (1/G of the panel, 4 KiB granules) to rank r over all its links at once and every rank then collects the
+ *            other pieces from their holders (RCCL: grouped ncclSend / ncclRecv; otherwise event-ordered pull copies).  Panels
+ *            below 1 MiB and the 512 KiB of inverses still travel as one rooted broadcast.  Pure data movement: same bits.
+ *            GPRC_MGPU_AUTO_EXCHANGE: gprc_mgpu_create runs gprc_mgpu_calibrate and keeps the faster form. */
+#define GPRC_MGPU_SCATTER_ALLGATHER 4
+#define GPRC_MGPU_AUTO_EXCHANGE 8
 typedef struct gprc_mgpu gprc_mgpu;
 typedef struct gprc_mgpu_model gprc_mgpu_model;
 GPRC_API int gprc_mgpu_create(const int* devices, int n_ranks, int flags, gprc_mgpu** mgpu_out);
 GPRC_API int gprc_mgpu_destroy(gprc_mgpu* mgpu);
 GPRC_API int gprc_mgpu_ranks(const gprc_mgpu* mgpu, int* n_ranks_out);
+/* Start-up calibration of the exchange step: both forms move a `doubles`-sized buffer from a rotating root to every rank
+ * `reps` times (after one warm-up), must deliver identical data, and scatter + all-gather is adopted when it is at least 10 %
+ * faster.  choice_out (may be NULL): 0 rooted broadcast, 1 scatter + all-gather; ms_out (may be NULL): the two times. */
+GPRC_API int gprc_mgpu_calibrate(gprc_mgpu* mgpu, int64_t doubles, int reps, int* choice_out, double* ms_out);
+/* 0 peer copies / rooted, 1 RCCL broadcast, 2 peer copies scatter + all-gather, 3 RCCL scatter + all-gather */
+GPRC_API int gprc_mgpu_exchange_mode(const gprc_mgpu* mgpu, int* mode_out);
+/* What the last fit (and the last predict) on this gprc_mgpu did -- a schedule-rehearsal record, not a benchmark.  out[0..n):
+ * [0] ranks G, [1] panels P, [2] exchange mode, [3] exchange operations issued, [4] bytes received per rank, [5] event record /
+ * wait pairs, [6] far-update passes, [7] look-ahead updates, [8] fit wall ms, [9] predict wall ms, then per rank r
+ * [10 + 3r] fill + sweep ms, [11 + 3r] alpha / logp ms (HIP events on the rank's main stream), [12 + 3r] predict ms of its slice. */
+GPRC_API int gprc_mgpu_stats(const gprc_mgpu* mgpu, double* out, int n);
 /* GPR$initialize, one Cholesky attempt (as gprc_gpr_fit) / the ten-step jitter loop (as gprc_gpr_fit_retry) */
 GPRC_API int gprc_mgpu_gpr_fit(gprc_mgpu* mgpu, int kernel, const double* params, int n_params, const double* X, int64_t d,
                       int64_t n, const double* y, double noise, gprc_mgpu_model** model_out);
@@ -283,7 +302,9 @@ GPRC_API int gprc_mgpu_gpr_get_alpha(gprc_mgpu_model* model, double* alpha_out);
 GPRC_API int gprc_mgpu_gpr_get_logp(gprc_mgpu_model* model, double* logp_out);
 GPRC_API int gprc_mgpu_gpr_get_noise(gprc_mgpu_model* model, double* noise_out);
 /* rank r's replica as an ordinary (borrowed) model handle: gprc_gpr_predict(pointwise = 0), gprc_model_get_L, ...
- * It belongs to the gprc_mgpu_model and dies with it. */
+ * It belongs to the gprc_mgpu_model and dies with it.
+ * Lifetime: a gprc_mgpu_model may be freed after its gprc_mgpu was destroyed (garbage collectors finalise in any order); its
+ * predict then fails with GPRC_ERR_ARG instead of touching the destroyed ranks. */
 GPRC_API int gprc_mgpu_model_rank(gprc_mgpu_model* model, int rank, gprc_model** model_out);
 GPRC_API int gprc_mgpu_model_free(gprc_mgpu_model* model);
 

@@ -118,7 +118,7 @@ def test_config4_size_identities():
     g = GPR(X, y, noise, cov_func(sqrexp, l=1.0))
     idx = np.r_[0:512, 30000:30512, n - 512:n]              # first, middle and last panels' points
     pr = g.predict(X[:, idx])
-    assert nerr(pr[:, 0], (y - noise * g.alpha)[idx]) <= 1e-9
+    assert nerr(pr[:, 0], (y - noise * g.alpha)[idx]) <= TOL    # the north star's 1e-10 (observed 2e-13)
     assert (pr[:, 1] > 0).all() and (pr[:, 1] < noise).all()
     pr2 = np.vstack([g.predict(X[:, idx[:700]]), g.predict(X[:, idx[700:]])])
     assert np.array_equal(pr, pr2)
@@ -136,70 +136,7 @@ def _grid(d, per):
     return np.ascontiguousarray(np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(-1, d).T)
 
 
-def _lapack_reference_subset(kind, X, y, Xs_sub, noise, slab=4096):
-    """Independent fp64 second opinion at sizes up to n = 65536 (K = 34 GB of the 288, factored in place): K is built in
-    row slabs with direct (x - y)^2 sums, factored by the vendor Cholesky (torch.linalg -> rocSOLVER potrf, rocBLAS
-    trsm / gemm), and only the SUBSET of test points is predicted.  Returns alpha, mean, var (numpy)."""
-    dev = torch.device("cuda:0")
-    Xt, yt, Xst = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (X.T, y, Xs_sub.T))
-    n, d = Xt.shape
-
-    def kern_into(out, A, B):
-        out.zero_()
-        for r in range(d):
-            out.add_((A[:, r, None] - B[None, :, r]) ** 2)
-        if kind == "sqrexp":
-            out.mul_(-0.5).exp_()
-        else:
-            out.div_(2 * 1.5).add_(1.0).pow_(-1.5)
-        return out
-
-    K = torch.empty(n, n, dtype=torch.float64, device=dev)
-    for c0 in range(0, n, slab):
-        c1 = min(n, c0 + slab)
-        kern_into(K[c0:c1, :], Xt[c0:c1], Xt)            # row slab of the symmetric K: contiguous in torch's row-major
-    K.diagonal().add_(noise)
-    # Vendor Cholesky, blocked by hand above 32768: torch.linalg.cholesky (hipSOLVER/rocSOLVER potrf) rejects n = 65536
-    # with "invalid configuration argument" on this stack, so the factorisation runs as a right-looking sweep over
-    # 16384-wide block columns built from the SAME vendor pieces -- potrf on the diagonal block, rocBLAS trsm and gemm
-    # for the rest -- in place in K's lower triangle.  Nothing of this library is involved.
-    nb = n if n <= 32768 else 16384
-    for k0 in range(0, n, nb):
-        k1 = min(n, k0 + nb)
-        K[k0:k1, k0:k1] = torch.linalg.cholesky(K[k0:k1, k0:k1])
-        if k1 < n:
-            Lkk = K[k0:k1, k0:k1]
-            K[k1:, k0:k1] = torch.linalg.solve_triangular(Lkk, K[k1:, k0:k1].T, upper=False).T     # L21 = K21 L11^-T
-            for j0 in range(k1, n, nb):                                                               # trailing block columns
-                j1 = min(n, j0 + nb)
-                K[j0:, j0:j1] -= K[j0:, k0:k1] @ K[j0:j1, k0:k1].T
-    L = K   # lower triangle = the factor; the strict upper part is never read below
-
-    def forward(B):      # L^-1 B by block forward substitution (B: n x m), in place
-        for k0 in range(0, n, nb):
-            k1 = min(n, k0 + nb)
-            if k0:
-                B[k0:k1] -= L[k0:k1, :k0] @ B[:k0]
-            B[k0:k1] = torch.linalg.solve_triangular(torch.tril(L[k0:k1, k0:k1]), B[k0:k1], upper=False)
-        return B
-
-    def backward(B):     # L^-T B
-        for k1 in range(n, 0, -nb):
-            k0 = max(0, k1 - nb)
-            if k1 < n:
-                B[k0:k1] -= L[k1:, k0:k1].T @ B[k1:]
-            B[k0:k1] = torch.linalg.solve_triangular(torch.tril(L[k0:k1, k0:k1]).T, B[k0:k1], upper=True)
-        return B
-
-    alpha = backward(forward(yt[:, None].clone()))[:, 0]
-    Ks = kern_into(torch.empty(n, Xst.shape[0], dtype=torch.float64, device=dev), Xt, Xst)
-    mean = Ks.T @ alpha
-    v = forward(Ks)
-    var = 1.0 - (v * v).sum(0)
-    out = alpha.cpu().numpy(), mean.cpu().numpy(), var.cpu().numpy()
-    del K, L, Ks, v
-    torch.cuda.empty_cache()
-    return out
+from tools.vendor_reference import lapack_reference_subset as _lapack_reference_subset   # also bench.py's independent leg
 
 
 @pytest.mark.parametrize("cfg,kind,n", [("c2", "sqrexp", 8192), ("c3", "rationalquadratic", 32768), ("c4", "sqrexp", 65536)])
@@ -237,3 +174,22 @@ def test_timed_configuration_full_grid_one_call(cfg, kind, n, orc):
         r = orc.gpr_fit_predict_blocked(kid, par, X, y, noise, np.ascontiguousarray(Xs[:, j]))
         assert r["info"] == 0
         assert nerr(full[j, 0], r["mean"]) <= TOL and nerr(full[j, 1], r["var"]) <= TOL
+
+
+def test_config4_eight_rank_protocol_with_virtual_ranks(tmp_path):
+    """BASELINE config 4 AS STATED -- "block-column Cholesky across 8 x MI355X" -- executed as a protocol on the one GPU a box
+    has: eight virtual ranks of gprc_mgpu_* (devices = {0 x 8}, panels exchanged by device copies) at the full n = 65536,
+    n* = 65536: 128 panels dealt to 8 owners, 127 look-ahead chains, batched far updates, ~10^3 recycled event pairs per rank,
+    replicated vector solves, the predict sliced in eight.  alpha, logp, mean and variance must be BITWISE equal to
+    gprc_gpr_fit / gprc_gpr_predict (R/GPRclass.R:127-170) with look-ahead, without it, and with the scatter + all-gather
+    form of the exchange.  The per-rank times it prints are a schedule rehearsal (eight ranks share one GPU), not scaling."""
+    import json, os
+    from test_gpu_c_abi import run_mgpu_client
+    from conftest import ROOT
+    recs = run_mgpu_client(tmp_path, 65536, 8, 65536, ["8:0", "8:2", "8:4"], timeout=900)
+    for r in recs[1:]:
+        assert r["ranks"] == 8 and r["panels"] == 128 and all(r["bitwise"].values()), r
+        assert abs(r["gb_in_per_rank"] - 7 / 8 * 17.3) < 0.5          # every rank receives the 7/8 of the factor it does not own
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "mgpu8_c4_rehearsal.json"), "w") as f:
+        json.dump(recs, f, indent=1)

@@ -96,3 +96,25 @@ def test_simulate_classification_reference_example():
     lat = d["model"].predict_latent(d["test_points"])
     assert nerr(lat[0], fs) <= 1e-9 and nerr(lat[1], vf) <= 1e-9
     assert np.mean(np.abs(d["residual"])) / 2 < 0.25 and s["Max."] in (0.0, 2.0)
+
+
+def test_config1_simulate_regression_n256():
+    """BASELINE.json configs[0] exactly: simulate_regression with n = 256 training points drawn by runif on [-1, 1] (d = 1),
+    y = f(x) + iid N(0, 0.1^2) noise, GPR$new(noise = 0.1, k = sqrexp l = 1), predict on the 10000-point equispaced grid
+    (R/simulation.R:86-103) -- on the HIP path, against the oracle on the same inputs at the north star's 1e-10; and the same
+    model through GPR(...)/predict directly (alpha, logp, L)."""
+    f = lambda x: 0.1 * x ** 3
+    k = cov_func(sqrexp, l=1.0)
+    s = simulate_regression(f, np.array([[-1.0, 1.0]]), training_size=256, observation_noise=iid_noise(lambda m, sd: np.random.default_rng(5).normal(0, sd, m), 0.1),
+                            noise=0.1, k=k, rng=np.random.default_rng(20261004))
+    d = s.data
+    X, y = d["model"].X, d["model"].y
+    assert X.shape == (1, 256) and d["test_points"].shape == (1, 10000) and d["predictions"].shape == (10000, 2)
+    assert d["test_points"][0, 0] == -1.0 and d["test_points"][0, -1] == 1.0
+    fit = orc.gpr_fit(orc.SQREXP, [1.0], X, y, 0.1)
+    mean, var = orc.gpr_predict(orc.SQREXP, [1.0], X, fit["L"], fit["alpha"], d["test_points"])
+    assert nerr(d["predictions"][:, 0], mean) <= 1e-10 and nerr(d["predictions"][:, 1], var) <= 1e-10
+    g = GPR(X, y, 0.1, k)
+    assert nerr(g.alpha, fit["alpha"]) <= 1e-10 and abs(g.logp - fit["logp"]) <= 1e-10 * abs(fit["logp"]) and nerr(g.L, fit["L"]) <= 1e-10
+    assert np.array_equal(g.predict(d["test_points"]), d["predictions"])      # the harness adds nothing to the numbers
+    assert s["Max."] < 0.2 and g.noise == 0.1
