@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <atomic>
 #include <cstring>
@@ -72,6 +73,7 @@ using namespace gprc;
 constexpr int SVC_TRACE_PANELS = 48;
 
 struct gprc_ctx {
+  uint64_t id = 0;             // unique per context ever created: a model remembers (pointer, id), so a LATER context at the same address is not mistaken for its own
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -102,6 +104,7 @@ enum ModelType { MODEL_GPR = 1, MODEL_GPC = 2 };
 
 struct gprc_model {
   gprc_ctx* ctx = nullptr;
+  uint64_t ctx_id = 0;
   int type = 0;
   KernelSpec ks{};
   int64_t n = 0, d = 0, n_pad = 0;
@@ -125,14 +128,15 @@ thread_local gprc_ctx* g_cur_ctx = nullptr;  // set by use_device(): whose pool 
 // at exit: Python does): gprc_model_free then must not touch the context's stream or block pool.
 static std::mutex g_live_mu;
 static std::vector<const gprc_ctx*> g_live_ctx;
-static void ctx_register(const gprc_ctx* c) { std::lock_guard<std::mutex> lk(g_live_mu); g_live_ctx.push_back(c); }
+static uint64_t g_next_ctx_id = 1;
+static void ctx_register(gprc_ctx* c) { std::lock_guard<std::mutex> lk(g_live_mu); c->id = g_next_ctx_id++; g_live_ctx.push_back(c); }
 static void ctx_unregister(const gprc_ctx* c) {
   std::lock_guard<std::mutex> lk(g_live_mu);
   g_live_ctx.erase(std::remove(g_live_ctx.begin(), g_live_ctx.end(), c), g_live_ctx.end());
 }
-static bool ctx_alive(const gprc_ctx* c) {
+static bool ctx_alive(const gprc_ctx* c, uint64_t id) {
   std::lock_guard<std::mutex> lk(g_live_mu);
-  return std::find(g_live_ctx.begin(), g_live_ctx.end(), c) != g_live_ctx.end();
+  return std::find(g_live_ctx.begin(), g_live_ctx.end(), c) != g_live_ctx.end() && c->id == id;
 }
 
 int pool_alloc(gprc_ctx* ctx, size_t bytes, void** out) {
@@ -237,7 +241,8 @@ int ws_get(gprc_ctx* ctx, int slot, int64_t count, double** out) {
       ctx->ws[slot] = nullptr;
       ctx->ws_cap[slot] = 0;
     }
-    GPRC_HIP(hipMalloc(&ctx->ws[slot], sizeof(double) * (size_t)count));
+    hipError_t e = hipMalloc(&ctx->ws[slot], sizeof(double) * (size_t)count);
+    if (e != hipSuccess) { ctx->ws[slot] = nullptr; return hip_fail(e, "hipMalloc(workspace)", __FILE__, __LINE__); }
     ctx->ws_cap[slot] = count;
   }
   *out = ctx->ws[slot];
@@ -364,7 +369,7 @@ int factor_group_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* w
 
 // inv (may be null): n_pad x NB doubles that receive, per panel, the explicit inverse of its diagonal block (transposed) -- what
 // launch_trsv works with; the factor service produces it on the side, the other schedules in one launch after the sweep
-int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev, double* inv) {
+int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev, double* inv, bool* used_service = nullptr) {
   hipStream_t s = ctx->stream;
   const int64_t P = n_pad / NB;
   // Groups: the shortest run of panels with >= `want` lower tiles (GPRC_FACTOR=<tiles>, =right: one group); a left-looking tile is
@@ -379,6 +384,7 @@ int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv,
   static const bool panel_steps = [] { const char* e = std::getenv("GPRC_PANEL"); return e && std::strcmp(e, "steps") == 0; }();
   static const int sv_env = [] { const char* e = std::getenv("GPRC_SERVICE"); return e ? std::atoi(e) : -1; }();
   const bool service = !panel_steps && sv_env != 0 && P >= 2 && !g_service_off.load();
+  if (used_service) *used_service = service;
   DevMem sync;   // flags of every panel + the counters; goes back to the pool when every launch below has been ordered behind it
   void* trace = nullptr;
   if (service) {
@@ -397,41 +403,57 @@ int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv,
     }
   }
   int launches = 0;
-  for (int64_t g0 = 0; g0 < P;) {
-    int64_t g1 = g0, tiles = 0;
-    while (g1 < P && tiles < want) { tiles += (int64_t)TPP * TPP * (P - g1) - TPP * (TPP - 1) / 2; ++g1; }
-    GPRC_TRY(launch_trailing_left(s, packed, n_pad, g0, g1));
-    if (service) {
-      GPRC_TRY(factor_group_service(ctx, packed, n_pad, winv, info_dev, inv, g0, g1, sync.p, trace, ++launches));
-    } else {
-      for (int64_t p = g0; p < g1; ++p) {
-        GPRC_TRY(factor_panel(ctx, packed, n_pad, p, winv, info_dev));
-        if (p + 1 < g1) GPRC_TRY(launch_trailing_update(s, packed, n_pad, p, p + 1, g1, 1));
+  auto sweep = [&]() -> int {
+    for (int64_t g0 = 0; g0 < P;) {
+      int64_t g1 = g0, tiles = 0;
+      while (g1 < P && tiles < want) { tiles += (int64_t)TPP * TPP * (P - g1) - TPP * (TPP - 1) / 2; ++g1; }
+      GPRC_TRY(launch_trailing_left(s, packed, n_pad, g0, g1));
+      if (service) {
+        GPRC_TRY(factor_group_service(ctx, packed, n_pad, winv, info_dev, inv, g0, g1, sync.p, trace, ++launches));
+      } else {
+        for (int64_t p = g0; p < g1; ++p) {
+          GPRC_TRY(factor_panel(ctx, packed, n_pad, p, winv, info_dev));
+          if (p + 1 < g1) GPRC_TRY(launch_trailing_update(s, packed, n_pad, p, p + 1, g1, 1));
+        }
       }
+      g0 = g1;
     }
-    g0 = g1;
+    return (inv && !service) ? launch_inv512(s, packed, n_pad, winv, inv, 0, P) : 0;
+  };
+  const int rc = sweep();
+  if (rc != 0 && service) {
+    // a launch failed half way: the persistent service kernel may still be running on the side stream and spinning on the flags in
+    // `sync` (its waits are bounded).  The block must not go back to the pool -- to be handed to somebody else -- before it has left.
+    (void)hipStreamSynchronize(ctx->side_stream);
+    (void)hipStreamSynchronize(s);
   }
-  return (inv && !service) ? launch_inv512(s, packed, n_pad, winv, inv, 0, P) : 0;
+  return rc;
 }
 
-int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_host, double* inv = nullptr);
+int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_host, double* inv = nullptr, bool* used_service = nullptr);
 
-// factor_all for callers that can rebuild the matrix: if the factor service timed out (see g_service_off), once per process the
-// matrix is rebuilt (refill) and factored again without the service instead of failing the call.
+// factor_all for callers that can rebuild the matrix.  If THIS call ran under the factor service and a device-side wait timed out
+// (see g_service_off), the service is switched off for the process (with one line on stderr: it is a permanent change of schedule),
+// the matrix is rebuilt (refill) and factored again with one fused launch per panel.  Decided per call, not once per process: two
+// host threads that time out in the same window (each with its own context) both retry.
 template <class Refill>
 int factor_all_or_refill(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_host, double* inv, Refill refill) {
-  int rc = factor_all(ctx, packed, n_pad, winv, info_host, inv);
-  if (rc == GPRC_ERR_HIP && *info_host == GPRC_INFO_WAIT_TIMEOUT && !g_service_off.exchange(true)) {
+  bool used_service = false;
+  int rc = factor_all(ctx, packed, n_pad, winv, info_host, inv, &used_service);
+  if (rc == GPRC_ERR_HIP && *info_host == GPRC_INFO_WAIT_TIMEOUT && used_service) {
+    if (!g_service_off.exchange(true))
+      std::fprintf(stderr, "gprc: a device-side wait of the factor service timed out (kernels of two streams did not run concurrently, e.g. under "
+                           "rocprofv3 --pmc); the service is now OFF for this process and the factorisation is repeated with one launch per panel\n");
     GPRC_TRY(refill());
     rc = factor_all(ctx, packed, n_pad, winv, info_host, inv);
   }
   return rc;
 }
 
-int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_host, double* inv) {
+int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_host, double* inv, bool* used_service) {
   hipStream_t s = ctx->stream;
   GPRC_HIP(hipMemsetAsync(ctx->info_dev, 0, sizeof(int), s));
-  GPRC_TRY(factor_all_async(ctx, packed, n_pad, winv, ctx->info_dev, inv));
+  GPRC_TRY(factor_all_async(ctx, packed, n_pad, winv, ctx->info_dev, inv, used_service));
   GPRC_HIP(hipMemcpyAsync(info_host, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
   GPRC_HIP(hipStreamSynchronize(s));
   if (*info_host < 0) {
@@ -503,7 +525,7 @@ void free_model(gprc_model* m) {
 int alloc_model(gprc_ctx* ctx, int type, const KernelSpec& ks, int64_t n, int64_t d, gprc_model** out) {
   gprc_model* m = new (std::nothrow) gprc_model();
   if (!m) { set_error("out of host memory"); return GPRC_ERR_NOMEM; }
-  m->ctx = ctx; m->type = type; m->ks = ks; m->n = n; m->d = d; m->n_pad = pad_up(n, NB);
+  m->ctx = ctx; m->ctx_id = ctx->id; m->type = type; m->ks = ks; m->n = n; m->d = d; m->n_pad = pad_up(n, NB);
   const int64_t n_pad = m->n_pad;
   int rc = 0;
   auto A = [&](double** p, int64_t cnt) {
@@ -685,6 +707,40 @@ int chunk_rows(const gprc_ctx* ctx, int64_t n_pad, int64_t ns) {
   if (rows < 256) rows = 256;
   const int64_t need = pad_up(ns, 128);
   return (int)(rows < need ? rows : need);
+}
+
+// The workspaces of a chunked pass over test points (K*^T chunk, its partial sums, k(x*, x*)): `rows` rows per chunk.
+// The budget (GPRC_CHUNK_BYTES, 40 GiB) is only a wish: the chunk is sized to what the device can actually give --
+// hipMemGetInfo's free figure plus what the context's slots already hold, less a reserve -- and if an allocation still fails
+// (another process took the memory in between; a fragmented heap) the chunk is HALVED and tried again, down to 256 rows, before
+// the call fails with GPRC_ERR_NOMEM.  Results do not depend on the chunking, bit for bit (a row's arithmetic depends on columns
+// only: test_chunked_predict_is_bitwise_chunk_invariant), so shrinking is free.  want_tmp: also slot 2 (`rows` doubles).
+int chunk_workspace(gprc_ctx* ctx, int64_t n_pad, int64_t ns, bool want_tmp, int64_t* rows_out, double** vt, double** part, double** tmp) {
+  int64_t rows = chunk_rows(ctx, n_pad, ns);
+  const int64_t per_row = (n_pad + predict_partials(n_pad) + 1) * (int64_t)sizeof(double);
+  static const bool ignore_meminfo = std::getenv("GPRC_IGNORE_MEMINFO") != nullptr;   // test hook: exercise the retry path itself
+  size_t free_b = 0, total_b = 0;
+  if (!ignore_meminfo && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    int64_t have = 0;
+    for (int i = 0; i < 3; ++i) have += ctx->ws_cap[i] * (int64_t)sizeof(double);
+    const int64_t avail = (int64_t)free_b + have - ((int64_t)256 << 20);   // 256 MiB stay free: the pool's small blocks, the runtime
+    const int64_t fit = (avail / per_row - ctx->vt_pad) / 256 * 256;
+    if (fit < rows) rows = fit < 256 ? 256 : fit;
+  } else {
+    (void)hipGetLastError();
+  }
+  for (;;) {
+    const int64_t ldv = rows + ctx->vt_pad;
+    int rc = ws_get(ctx, 0, ldv * n_pad, vt);
+    if (rc == 0) rc = ws_get(ctx, 1, rows * predict_partials(n_pad), part);
+    if (rc == 0 && want_tmp) rc = ws_get(ctx, 2, rows, tmp);
+    if (rc == 0) break;
+    if (rc != GPRC_ERR_NOMEM || rows <= 256) return rc;
+    pool_trim(ctx);                                    // cached blocks of earlier calls go back first
+    rows = std::max<int64_t>(256, rows / 2 / 256 * 256);
+  }
+  *rows_out = rows;
+  return 0;
 }
 
 }  // namespace
@@ -888,10 +944,9 @@ int gprc_fit_gradient(gprc_ctx* ctx, int kernel, const double* params, int n_par
   GPRC_TRY(kinv.alloc(n_pad));
   GPRC_TRY(S.alloc(2 * n));
   // diag(K^-1): rows of L^-T, chunk by chunk
-  const int64_t rows = chunk_rows(ctx, n_pad, n);
-  double *vt = nullptr, *red = nullptr;
-  GPRC_TRY(ws_get(ctx, 0, rows * n_pad, &vt));
-  GPRC_TRY(ws_get(ctx, 1, rows * predict_partials(n_pad), &red));
+  int64_t rows = 0;
+  double *vt = nullptr, *red = nullptr, *unused = nullptr;
+  GPRC_TRY(chunk_workspace(ctx, n_pad, n, false, &rows, &vt, &red, &unused));
   for (int64_t s0 = 0; s0 < n; s0 += rows) {
     const int64_t mcur = std::min<int64_t>(rows, n - s0), m_pad = pad_up(mcur, 128);
     GPRC_TRY(launch_set_identity_rows(s, vt, m_pad, m_pad, n_pad, s0));
@@ -950,12 +1005,16 @@ int gprc_gpr_predict(gprc_model* m, const double* X_star, int64_t ns, int pointw
   GPRC_TRY(mean.set(mean_out, ns));
   GPRC_TRY(var.set(var_out, pointwise ? ns : ns * ns));
 
-  const int64_t rows = pointwise ? chunk_rows(ctx, n_pad, ns) : pad_up(ns, 128);
-  const int64_t ldv = rows + ctx->vt_pad;  // one leading dimension for every chunk
+  int64_t rows = pad_up(ns, 128);
   struct { double* p; } vt, part, tmp;
-  GPRC_TRY(ws_get(ctx, 0, ldv * n_pad, &vt.p));
-  GPRC_TRY(ws_get(ctx, 1, rows * predict_partials(n_pad), &part.p));
-  GPRC_TRY(ws_get(ctx, 2, rows, &tmp.p));
+  if (pointwise) {
+    GPRC_TRY(chunk_workspace(ctx, n_pad, ns, true, &rows, &vt.p, &part.p, &tmp.p));
+  } else {   // the full covariance needs all of v at once: no chunking to fall back on
+    GPRC_TRY(ws_get(ctx, 0, (rows + ctx->vt_pad) * n_pad, &vt.p));
+    GPRC_TRY(ws_get(ctx, 1, rows * predict_partials(n_pad), &part.p));
+    GPRC_TRY(ws_get(ctx, 2, rows, &tmp.p));
+  }
+  const int64_t ldv = rows + ctx->vt_pad;  // one leading dimension for every chunk
   double* kss_c = tmp.p;
 
   if (pointwise) {
@@ -1031,7 +1090,7 @@ int gprc_gpr_get_noise(gprc_model* m, double* noise_out) {
 }
 int gprc_model_free(gprc_model* m) {
   if (!m) return 0;
-  if (m->ctx && !ctx_alive(m->ctx)) {   // the context went first: its stream is gone (and was synchronised), its pool too
+  if (m->ctx && !ctx_alive(m->ctx, m->ctx_id)) {   // the context went first: its stream is gone (and was synchronised), its pool too
     m->ctx = nullptr;                   // -> the buffers go straight back to the driver
     (void)hipDeviceSynchronize();
   }
@@ -1140,12 +1199,10 @@ int gprc_gpc_predict_latent(gprc_model* m, const double* X_star, int64_t ns, dou
   GPRC_TRY(xs.set(s, X_star, d * ns));
   GPRC_TRY(fs.set(fs_bar_out, ns));
   GPRC_TRY(vf.set(Vfs_out, ns));
-  const int64_t rows = chunk_rows(ctx, n_pad, ns);
-  const int64_t ldv = rows + ctx->vt_pad;
+  int64_t rows = 0;
   struct { double* p; } vt, part, tmp;
-  GPRC_TRY(ws_get(ctx, 0, ldv * n_pad, &vt.p));
-  GPRC_TRY(ws_get(ctx, 1, rows * predict_partials(n_pad), &part.p));
-  GPRC_TRY(ws_get(ctx, 2, rows, &tmp.p));
+  GPRC_TRY(chunk_workspace(ctx, n_pad, ns, true, &rows, &vt.p, &part.p, &tmp.p));
+  const int64_t ldv = rows + ctx->vt_pad;
   for (int64_t s0 = 0; s0 < ns; s0 += rows) {   // R/GPCclass.R:112-115: m->alpha holds g = (y+1)/2 - P, the stored columns are sqrt(W) * K_star
     const int64_t mcur = (ns - s0 < rows) ? ns - s0 : rows;
     GPRC_TRY(predict_chunk(m, xs.dev + s0 * d, mcur, vt.p, ldv, part.p, tmp.p, m->sw, fs.dev + s0, vf.dev + s0));
@@ -1439,7 +1496,7 @@ int gprc_gpr_model_from_device(gprc_ctx* ctx, int kernel, const double* params, 
   GPRC_TRY(make_spec(kernel, params, n_params, d, &ks));
   gprc_model* m = new (std::nothrow) gprc_model();
   if (!m) { set_error("out of host memory"); return GPRC_ERR_NOMEM; }
-  m->ctx = ctx; m->type = MODEL_GPR; m->ks = ks; m->n = n; m->d = d; m->n_pad = pad_up(n, NB);
+  m->ctx = ctx; m->ctx_id = ctx->id; m->type = MODEL_GPR; m->ks = ks; m->n = n; m->d = d; m->n_pad = pad_up(n, NB);
   m->borrowed = true;
   m->X = const_cast<double*>(X); m->y = const_cast<double*>(y); m->packed = packed; m->winv = winv; m->alpha = alpha;
   m->noise = noise; m->logp = logp;

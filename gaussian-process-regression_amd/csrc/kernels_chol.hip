@@ -14,6 +14,7 @@
 // The trailing update is the dominant kernel of the whole path: n^3/3 of the fit and n^2 n* of the
 // predict go through gemm_tile_128().
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "gprc_internal.h"
@@ -799,6 +800,9 @@ __global__ __launch_bounds__(256, 2) void trailing_range_kernel(double* packed, 
 // loads, agent acquire fence + vmcnt(0), workgroup barrier, plain / LDS-DMA loads).
 // ------------------------------------------------------------------------------------------------
 struct PanelSync { int ticket; int failed; int W[4]; int E[4]; int R[4]; int LA; int pad; };   // 16 ints, zeroed before the launch
+// Bound of every device-side dependency wait: WALL time (s_memrealtime, 100 MHz), not a poll count -- a busy, shared GPU slows the
+// polls down but must not shorten the patience.  Legitimate waits are below 10 ms (one trailing update at n <= 24576).
+constexpr unsigned long long WAIT_LIMIT_TICKS = 400000000ULL;   // 4 s
 // (factor service only -- LA: finished sub-steps of the four look-ahead strips, 16 when rows [NB, 2 NB) of the panel are final;
 //  E[0], E[1]: blocks (s, j <= s-2) the diagonal strips s = 2, 3 have finished)
 
@@ -806,15 +810,17 @@ __device__ __forceinline__ void panel_flag_wait(int* flag, PanelSync* sy, int* i
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own stores: its team-mates re-read them after the barrier
   if (threadIdx.x == 0) {
     int spins = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
       __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 255) != 0) continue;
       // somebody has already given up (e.g. a profiler that serialises dispatches keeps producer and consumer kernels apart): every
       // later wait of the factorisation returns at once instead of running out its own bound
-      if ((spins & 255) == 0 && __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
+      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
       // exit condition every wave reaches (a producer that never publishes must not leave this workgroup spinning on the GPU
-      // for ever; ~2^23 polls is several seconds, legitimate waits are below a millisecond): give up, let the grid drain, and tell
-      // the host through the ONE word it always reads after a factorisation -- info = GPRC_INFO_WAIT_TIMEOUT (< 0; LAPACK infos are > 0)
-      if (++spins > (1 << 23)) {
+      // for ever): after WAIT_LIMIT_TICKS of wall time give up, let the grid drain, and tell the host through the ONE word it
+      // always reads after a factorisation -- info = GPRC_INFO_WAIT_TIMEOUT (< 0; LAPACK infos are > 0)
+      if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) {
         __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
         break;
@@ -840,10 +846,12 @@ __device__ __forceinline__ void panel_ready_wait(int* ctr, int need, PanelSync* 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (threadIdx.x == 0) {
     int spins = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
       __builtin_amdgcn_s_sleep(2);
-      if ((spins & 255) == 0 && __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
-      if (++spins > (1 << 22)) {   // bounded (see panel_flag_wait): seconds, where the longest legitimate wait -- one trailing update at n <= 24576 -- is ~10 ms
+      if ((++spins & 255) != 0) continue;
+      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) {   // bounded in wall time (see panel_flag_wait)
         __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
         break;
@@ -1133,12 +1141,14 @@ __global__ __launch_bounds__(512) void panel_service_kernel(double* packed, int6
 
 // First kernel of the caller's stream: one wave that returns once every service workgroup is resident.  Whatever waits on the
 // service is ordered behind it, so a GPU full of waiting workgroups can never keep the service out.
-__global__ void service_gate_kernel(int* alive, int need, int* info) {
+// limit_ticks: patience in s_memrealtime ticks (WAIT_LIMIT_TICKS; the test hook GPRC_TEST_SERVICE_TIMEOUT passes 0 with an
+// unreachable `need` once: the gate gives up at its first look, every wait behind it returns at once, info = GPRC_INFO_WAIT_TIMEOUT).
+__global__ void service_gate_kernel(int* alive, int need, int* info, unsigned long long limit_ticks) {
   if (threadIdx.x == 0) {
-    int spins = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(alive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 >= limit_ticks) { atomicExch(info, GPRC_INFO_WAIT_TIMEOUT); break; }
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1 << 22)) { atomicExch(info, GPRC_INFO_WAIT_TIMEOUT); break; }
     }
   }
 }
@@ -1328,7 +1338,12 @@ int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* w
 int launch_service_gate(hipStream_t s, int64_t n_pad, int* info_dev, void* sync, int launches) {
   const int64_t P = n_pad / NB;
   int* ready = reinterpret_cast<int*>(static_cast<char*>(sync) + (size_t)P * sizeof(PanelSync));
-  hipLaunchKernelGGL(service_gate_kernel, dim3(1), dim3(64), 0, s, ready + 3 * P, SERVICE_WGS * launches, info_dev);
+  // GPRC_TEST_SERVICE_TIMEOUT=1 (test hook): the FIRST gate of the process waits for a residency count that cannot be reached and
+  // gives up at once -- the timeout / refill / service-off path of the fit entry points without a profiler.
+  static std::atomic<bool> fire{std::getenv("GPRC_TEST_SERVICE_TIMEOUT") != nullptr};
+  const bool forced = fire.exchange(false);
+  hipLaunchKernelGGL(service_gate_kernel, dim3(1), dim3(64), 0, s, ready + 3 * P, forced ? (1 << 30) : SERVICE_WGS * launches, info_dev,
+                     forced ? 0ULL : WAIT_LIMIT_TICKS);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

@@ -14,6 +14,16 @@
  *    context's GPU (the resident-data case: bench.py, the multi-GPU driver).  The library asks the HIP
  *    runtime which it is; host data is staged through the context's stream, device data is used in
  *    place.  Inputs are borrowed for the duration of the call only;
+ *  - ORDERING of device data: every kernel of a call runs on the CONTEXT'S stream (and on side streams the
+ *    library orders behind it), never on the null stream, and a context that creates its own stream creates it
+ *    non-blocking -- it is NOT ordered with the caller's streams.  Device inputs must therefore be complete on,
+ *    or ordered before, the context's stream when the call is made, and device outputs are ready on that stream
+ *    when it returns (the fit / predict entry points also synchronise it; the gprc_dev_* building blocks are
+ *    asynchronous).  Two ways to satisfy it: (a) pass YOUR stream to gprc_ctx_create -- data produced and
+ *    consumed on that stream needs no synchronisation at all; (b) keep the context's own stream and finish the
+ *    producers first (hipStreamSynchronize / hipDeviceSynchronize, or an event the context's stream cannot see
+ *    is not enough).  A copy still in flight on another stream when the first kernel starts is a data race
+ *    (seen once in this repository's own tests: a 1.8 GB clone overwrote the first panel's update);
  *  - return value: 0 = ok; > 0 = LAPACK-style info (order of the first leading minor that is not
  *    positive definite -- what R's chol() reports, R/GPRclass.R:142); < 0 = gprc_status error, with
  *    text in gprc_last_error().  The library never aborts, exits or throws across this boundary;
@@ -73,11 +83,16 @@ GPRC_API int gprc_abi_version(void);
 /* text of the last error on the calling thread ("" if none); valid until the next failing call */
 GPRC_API const char* gprc_last_error(void);
 GPRC_API int gprc_device_count(int* count_out);
-/* stream: a hipStream_t owned by the caller (e.g. torch's current stream), or NULL to let the
- * context create and own one. */
+/* stream: a hipStream_t owned by the caller (e.g. a torch.cuda.Stream's handle), or NULL to let the
+ * context create and own a non-blocking one (see "ORDERING of device data" above; note that the legacy
+ * default stream's handle IS NULL, so it cannot be handed over this way). */
 GPRC_API int gprc_ctx_create(int device, void* stream, gprc_ctx** ctx_out);
 GPRC_API int gprc_ctx_destroy(gprc_ctx* ctx);
-/* Gives the device memory a context keeps for reuse back to the driver: the free-list of blocks released by earlier
+/* GPR$predict / GPC$predict_class work through the test points in chunks of rows of K*^T.  The chunk is sized from
+ * GPRC_CHUNK_BYTES (default 40 GiB) but never beyond what hipMemGetInfo reports free; if an allocation still fails
+ * the chunk is halved and tried again (down to 256 rows) before the call returns GPRC_ERR_NOMEM.  Results do not
+ * depend on the chunking, bit for bit.
+ * Gives the device memory a context keeps for reuse back to the driver: the free-list of blocks released by earlier
  * calls (exact-size reuse; fit() evaluates the same n over and over; capped by GPRC_POOL_BYTES, default 16 GiB, 0 = off)
  * and the predict workspaces.  Never needed for correctness. */
 GPRC_API int gprc_ctx_trim(gprc_ctx* ctx);

@@ -573,3 +573,94 @@ def test_not_positive_definite_through_the_factor_service():
     assert g.noise > 0 and any("Noise got changed" in str(x.message) for x in w)
     assert np.all(np.isfinite(g.alpha))
     g.close()
+
+
+def _child(code, env=None, timeout=600):
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    pre = "import sys; sys.path.insert(0, %r)\nimport numpy as np, hashlib\nimport gprc_amd\nfrom gprc_amd import GPR, GPC, cov_func, sqrexp, _native as nat\n" % (os.path.dirname(here),)
+    r = subprocess.run([sys.executable, "-c", pre + code], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    return r
+
+
+def test_service_timeout_refills_and_matches_the_service_result():
+    """The fallback include/gprc_native.h promises, exercised without a profiler: GPRC_TEST_SERVICE_TIMEOUT makes the first service gate
+    of a (child) process give up at once, info becomes GPRC_INFO_WAIT_TIMEOUT, and the fit entry points -- GPR, the GPC's IRLS loop --
+    switch the service off (one line on stderr), rebuild the matrix and factor again.  Same bits as a fit under the service."""
+    code = (
+        "rng = np.random.default_rng(5); X = rng.uniform(-1, 1, (3, 2900)); y = rng.normal(size=2900); Xs = rng.uniform(-1, 1, (3, 200))\n"
+        "assert nat.lib().gprc_factor_service(-1) == 1\n"
+        "g = GPR(X, y, 0.1, cov_func(sqrexp, l=0.8))\n"
+        "assert nat.lib().gprc_factor_service(-1) == 0, 'the forced timeout should have switched the service off'\n"
+        "h = hashlib.sha256(g.alpha.tobytes() + np.float64(g.logp).tobytes() + g.predict(Xs).tobytes()).hexdigest()\n"
+        "print('DIGEST', h)\n")
+    r = _child(code, {"GPRC_TEST_SERVICE_TIMEOUT": "1"})
+    assert "service is now OFF" in r.stderr
+    import hashlib
+    rng = np.random.default_rng(5); X = rng.uniform(-1, 1, (3, 2900)); y = rng.normal(size=2900); Xs = rng.uniform(-1, 1, (3, 200))
+    assert nat.lib().gprc_factor_service(-1) == 1
+    g = GPR(X, y, 0.1, cov_func(sqrexp, l=0.8))
+    want = hashlib.sha256(g.alpha.tobytes() + np.float64(g.logp).tobytes() + g.predict(Xs).tobytes()).hexdigest()
+    g.close()
+    assert ("DIGEST " + want) in r.stdout
+
+
+def test_predict_chunk_shrinks_to_the_memory_that_is_there():
+    """gprc_gpr_predict sizes its K*^T chunk from hipMemGetInfo and, when an allocation still fails, halves the chunk and tries again
+    (down to 256 rows) instead of failing the call (GPRC_CHUNK_BYTES is a wish, not a promise).  A child process hogs the GPU down to
+    ~3 GiB free, then predicts 65536 points against n = 8192 -- 4.3 GB in one chunk -- (a) sized by the free-memory figure, (b) with that
+    figure ignored (GPRC_IGNORE_MEMINFO: the first hipMalloc fails, the halved chunk fits).  Chunking never changes a bit."""
+    code = (
+        "import torch\n"
+        "rng = np.random.default_rng(6); X = rng.uniform(-1, 1, (8, 8192)); y = rng.normal(size=8192); Xs = rng.uniform(-1, 1, (8, 65536))\n"
+        "g = GPR(X, y, 0.1, cov_func(sqrexp, l=1.0))\n"
+        "free, total = torch.cuda.mem_get_info()\n"
+        "hog = torch.empty(int(free - (3 << 30)), dtype=torch.uint8, device='cuda'); torch.cuda.synchronize()\n"
+        "pr = g.predict(Xs)\n"
+        "print('FREE_GIB', torch.cuda.mem_get_info()[0] / 2**30)\n"
+        "print('DIGEST', hashlib.sha256(pr.tobytes()).hexdigest())\n")
+    rng = np.random.default_rng(6); X = rng.uniform(-1, 1, (8, 8192)); y = rng.normal(size=8192); Xs = rng.uniform(-1, 1, (8, 65536))
+    import hashlib
+    g = GPR(X, y, 0.1, cov_func(sqrexp, l=1.0))
+    want = hashlib.sha256(g.predict(Xs).tobytes()).hexdigest()
+    g.close()
+    nat.check(nat.lib().gprc_ctx_trim(nat.default_context().handle))      # this process's own 4.3 GB chunk goes back first
+    for env in ({}, {"GPRC_IGNORE_MEMINFO": "1"}):
+        r = _child(code, env)
+        assert ("DIGEST " + want) in r.stdout, (env, r.stdout[-500:])
+
+
+def test_device_data_on_the_contexts_own_stream_needs_no_synchronisation():
+    """The ordering rule of include/gprc_native.h for DEVICE pointers: the library reads and writes them on the context's stream, so
+    data produced on THAT stream is ordered by the stream itself.  Here the context is created on a torch stream, the inputs are
+    uploaded, the outputs allocated and the results read back on that stream -- with NO torch.cuda.synchronize() anywhere between
+    torch's work and the library's (the other tests, whose contexts own a private non-blocking stream, must synchronise)."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(12)
+    d, n, ns = 4, 3300, 900
+    X = np.asfortranarray(rng.uniform(-1, 1, (d, n))); y = rng.normal(size=n); Xs = np.asfortranarray(rng.uniform(-1, 1, (d, ns)))
+    host = GPR(X, y, 0.1, cov_func(sqrexp, l=0.9))
+    want = host.predict(Xs)
+    st = torch.cuda.Stream()
+    ctx = nat.Context(0, st.cuda_stream)
+    _, pp, npar = nat.params_array([0.9])
+    for rep in range(3):
+        with torch.cuda.stream(st):
+            big = torch.randn(1 << 26, device="cuda")                       # ~0.3 s of queued work in front of the uploads
+            for _ in range(20):
+                big = big * 1.0000001
+            Xd = torch.from_numpy(X.T.copy()).pin_memory().to("cuda", non_blocking=True)
+            yd = torch.from_numpy(y).pin_memory().to("cuda", non_blocking=True)
+            Xsd = torch.from_numpy(Xs.T.copy()).pin_memory().to("cuda", non_blocking=True)
+            mean = torch.full((ns,), float("nan"), dtype=torch.float64, device="cuda")
+            var = torch.full((ns,), float("nan"), dtype=torch.float64, device="cuda")
+            model = C.c_void_p()
+            nat.check(nat.lib().gprc_gpr_fit(ctx.handle, nat.SQREXP, pp, npar, Xd.data_ptr(), d, n, yd.data_ptr(), 0.1, C.byref(model)))
+            nat.check(nat.lib().gprc_gpr_predict(model, Xsd.data_ptr(), ns, 1, mean.data_ptr(), var.data_ptr()))
+            got = torch.stack([mean, var], 1).cpu().numpy()
+        nat.lib().gprc_model_free(model)
+        assert np.array_equal(got, want), rep
+    ctx.close()
+    host.close()
