@@ -343,7 +343,10 @@ __device__ __forceinline__ const double* strip_ktile(const double* B, int64_t ld
 // zero above the diagonal) -- the factor role hands the updated diagonal block to the factorisation without the round trip
 // through memory (one more workgroup barrier than without: every wave must be past its last operand read, the image overlaps
 // the staging buffers).
-template <bool SET, bool SEG = false, bool SEGA = false, bool SSQ = false, bool LDSOUT = false>
+// ILV: the main loop with every non-MFMA instruction in the shadow of an MFMA (below) -- the throughput kernels; false keeps the
+// block-structured loop for the roles of the fused panel / service kernels, which inline this function several times and spill
+// with the larger body (their tiles are short -- K = 128..384 -- and paced by flags, not by the loop).
+template <bool SET, bool SEG = false, bool SEGA = false, bool SSQ = false, bool LDSOUT = false, bool ILV = true>
 __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                                               int64_t ldb, int K, double* smem, int64_t brow = 0, int64_t arow = 0, int kt0 = 0,
                                               double* ssq = nullptr, int tid = -1, double* lds_out = nullptr) {
@@ -399,6 +402,110 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
   double a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
   read_ops(As + wr * 64 + foff, Bs + wc * 64 + foff, 0, a0, b0);
   read_ops(As + wr * 64 + foff, Bs + wc * 64 + foff, 1, a1, b1);
+#ifndef GPRC_CORE_CLUMPED
+  constexpr bool interleaved = ILV;
+#else
+  constexpr bool interleaved = false;
+#endif
+  if constexpr (interleaved) {
+  // ---- Main loop, every non-MFMA instruction in the shadow of an MFMA (round 3) ----------------------------------------------
+  // Counters on the shipped loop (profiles/r03_c4_core_counters.txt): the MFMA pipes were busy 91.7 % of the kernel's cycles at
+  // 2.37 GHz, and per 64 MFMAs a wave issues 73 other instructions -- 16 ds_read2, 8 LDS-DMA with their m0 / address set-up, the
+  // s_waitcnt / s_barrier, loop arithmetic.  In the block-structured loop they sat in CLUMPS between the 16-MFMA blocks: four
+  // operand-read groups and, once per k-tile, vmcnt(0) + barrier + 8 DMA issues + 4 reads with nothing but the block's last MFMA
+  // in flight.  A wave is in order: while it works through a clump it issues no MFMA, and its SIMD's pipe runs dry unless the
+  // partner wave happens to be inside a block (a wave alone on its SIMD reached 75 %).  Here every MFMA is followed by at most
+  // one other operation (a ds_read2, or one DMA with its set-up), the barrier sits BETWEEN two MFMAs of block 2 with four MFMAs
+  // of the same wave still queued on the pipe, and the order is pinned by a sched_barrier after every statement.  The products,
+  // their k order and the accumulator each one lands in are unchanged: identical bits.
+  //   block 0 (a0,b0): reads (t,2) after MFMAs 1,3,5,7          block 1 (a1,b1): reads (t,3) after 1,3,5,7
+  //   block 2 (a2,b2): MFMAs 0-3 | lgkmcnt(0) vmcnt(0) s_barrier | reads (t+1,0) after 4,5,6,7 | DMA slice i of tile t+2 after 8+i
+  //   block 3 (a3,b3): reads (t+1,1) after 1,3,5,7
+#define GPRC_SB __builtin_amdgcn_sched_barrier(0);
+  // (timing experiments only -- wrong results: GPRC_EXP_NOVM drops the wait for the landed DMA, GPRC_EXP_NOBAR the workgroup barrier)
+#ifdef GPRC_EXP_NOVM
+#define GPRC_TILE_WAIT asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+#define GPRC_TILE_WAIT asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+#ifdef GPRC_EXP_NOBAR
+#define GPRC_TILE_BARRIER
+#else
+#define GPRC_TILE_BARRIER __builtin_amdgcn_s_barrier();
+#endif
+#define GPRC_M(A_, B_, i) acc[(i) >> 2][(i) & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(B_[(i) & 3], A_[(i) >> 2], acc[(i) >> 2][(i) & 3], 0, 0, NEG); GPRC_SB
+  // one ds_read2_b64 each: RA r = 0, 1 -> a[2r], a[2r+1]; RB r = 0, 1 -> b[2r], b[2r+1]
+#define GPRC_RA(Ap_, kk, r, A_) A_[2 * (r)] = (Ap_)[(kk) * 4 * G_LDT + (2 * (r)) * 16]; A_[2 * (r) + 1] = (Ap_)[(kk) * 4 * G_LDT + (2 * (r) + 1) * 16]; GPRC_SB
+#define GPRC_RB(Bp_, kk, r, B_) B_[2 * (r)] = (Bp_)[(kk) * 4 * G_LDT + (2 * (r)) * 16]; B_[2 * (r) + 1] = (Bp_)[(kk) * 4 * G_LDT + (2 * (r) + 1) * 16]; GPRC_SB
+#define GPRC_BLOCK_R(A_, B_, Ap_, Bp_, kk, RA_, RB_, cond)                                                          \
+  GPRC_M(A_, B_, 0) GPRC_M(A_, B_, 1) if (cond) { GPRC_RA(Ap_, kk, 0, RA_) }                                        \
+  GPRC_M(A_, B_, 2) GPRC_M(A_, B_, 3) if (cond) { GPRC_RA(Ap_, kk, 1, RA_) }                                        \
+  GPRC_M(A_, B_, 4) GPRC_M(A_, B_, 5) if (cond) { GPRC_RB(Bp_, kk, 0, RB_) }                                        \
+  GPRC_M(A_, B_, 6) GPRC_M(A_, B_, 7) if (cond) { GPRC_RB(Bp_, kk, 1, RB_) }                                        \
+  GPRC_M(A_, B_, 8) GPRC_M(A_, B_, 9) GPRC_M(A_, B_, 10) GPRC_M(A_, B_, 11) GPRC_M(A_, B_, 12) GPRC_M(A_, B_, 13) GPRC_M(A_, B_, 14) GPRC_M(A_, B_, 15)
+#define GPRC_DMA(i, more2)                                                                                           \
+  if (more2) {                                                                                                      \
+    if ((i) < 4) __builtin_amdgcn_global_load_lds((gptr_t)(Ag + (int64_t)(4 * (i)) * ldak), (lptr_t)(As + cur + srow + 4 * (i) * G_LDT), 16, 0, 0); \
+    else __builtin_amdgcn_global_load_lds((gptr_t)(Bg + (int64_t)(4 * ((i) - 4)) * ldbk), (lptr_t)(Bs + cur + srow + 4 * ((i) - 4) * G_LDT), 16, 0, 0); \
+    GPRC_SB                                                                                                         \
+  }
+  // one k-tile; more1 / more2: a tile kt+1 / kt+2 exists (compile-time true in the steady-state loop, so that it has no branches)
+#define GPRC_KTILE(more1, more2)                                                                                     \
+  {                                                                                                                 \
+    const int cur = (kt & 1) * G_BUF, nxt = G_BUF - cur;                                                            \
+    const double* Ac = As + cur + wr * 64 + foff;                                                                   \
+    const double* Bc = Bs + cur + wc * 64 + foff;                                                                   \
+    const double* An = As + nxt + wr * 64 + foff;                                                                   \
+    const double* Bn = Bs + nxt + wc * 64 + foff;                                                                   \
+    GPRC_SB                                                                                                         \
+    GPRC_BLOCK_R(a0, b0, Ac, Bc, 2, a2, b2, true)                                                                   \
+    GPRC_BLOCK_R(a1, b1, Ac, Bc, 3, a3, b3, true)                                                                   \
+    GPRC_M(a2, b2, 0) GPRC_M(a2, b2, 1) GPRC_M(a2, b2, 2) GPRC_M(a2, b2, 3)                                         \
+    if (more1) {                                                                                                    \
+      /* this wave's reads of buffer `cur` have returned (lgkmcnt) and its share of tile kt+1 has landed (vmcnt); after the */ \
+      /* barrier that holds for every wave: tile kt+1 may be read and buffer `cur` overwritten */                   \
+      GPRC_TILE_WAIT                                                                                                \
+      GPRC_TILE_BARRIER                                                                                             \
+      GPRC_SB                                                                                                       \
+      if (more2) {                                                                                                  \
+        if constexpr (SEGA || SEG) {                                                                                \
+          const bool boundary = ((kt0 + kt + 2) % (NB / 16)) == 0;                                                  \
+          if constexpr (SEGA) { if (boundary) Ag = strip_ktile<true>(A, lda, arow, kt0 + kt + 2, lane, wave, ldak); else Ag += (int64_t)G_KB * ldak; } \
+          if constexpr (SEG) { if (boundary) Bg = strip_ktile<true>(B, ldb, brow, kt0 + kt + 2, lane, wave, ldbk); else Bg += (int64_t)G_KB * ldbk; } \
+        }                                                                                                           \
+        GPRC_SB                                                                                                     \
+      }                                                                                                             \
+    }                                                                                                               \
+    GPRC_M(a2, b2, 4) if (more1) { GPRC_RA(An, 0, 0, a0) }                                                          \
+    GPRC_M(a2, b2, 5) if (more1) { GPRC_RA(An, 0, 1, a0) }                                                          \
+    GPRC_M(a2, b2, 6) if (more1) { GPRC_RB(Bn, 0, 0, b0) }                                                          \
+    GPRC_M(a2, b2, 7) if (more1) { GPRC_RB(Bn, 0, 1, b0) }                                                          \
+    GPRC_M(a2, b2, 8) GPRC_DMA(0, more2) GPRC_M(a2, b2, 9) GPRC_DMA(4, more2) GPRC_M(a2, b2, 10) GPRC_DMA(1, more2) GPRC_M(a2, b2, 11) GPRC_DMA(5, more2) \
+    GPRC_M(a2, b2, 12) GPRC_DMA(2, more2) GPRC_M(a2, b2, 13) GPRC_DMA(6, more2) GPRC_M(a2, b2, 14) GPRC_DMA(3, more2) GPRC_M(a2, b2, 15) GPRC_DMA(7, more2) \
+    if (more2) {                                                                                                    \
+      if constexpr (!SEGA) Ag += (int64_t)G_KB * lda;                                                               \
+      if constexpr (!SEG) Bg += (int64_t)G_KB * ldb;                                                                \
+    }                                                                                                               \
+    GPRC_BLOCK_R(a3, b3, An, Bn, 1, a1, b1, more1)                                                                  \
+  }
+  {
+    int kt = 0;
+    for (; kt + 2 < KT; ++kt) GPRC_KTILE(true, true)
+    for (; kt < KT; ++kt) {
+      const bool more1 = kt + 1 < KT;
+      GPRC_KTILE(more1, false)
+    }
+  }
+#undef GPRC_KTILE
+#undef GPRC_TILE_WAIT
+#undef GPRC_TILE_BARRIER
+#undef GPRC_DMA
+#undef GPRC_BLOCK_R
+#undef GPRC_RA
+#undef GPRC_RB
+#undef GPRC_M
+#undef GPRC_SB
+  } else {
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = (kt & 1) * G_BUF, nxt = G_BUF - cur;
     const double* Ac = As + cur + wr * 64 + foff;
@@ -440,6 +547,8 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
     if (kt + 1 < KT) read_ops(An, Bn, 1, a1, b1);
     mma_step<NEG>(a3, b3, acc);
     __builtin_amdgcn_sched_barrier(0);
+  }
+
   }
 
 #pragma unroll
@@ -900,7 +1009,7 @@ __device__ __forceinline__ void panel_factor_role(double* sm, double* pan, int64
     double* Dn = pan + (int64_t)(j + 1) * NBI + (int64_t)(j + 1) * NBI * ld;      // block (j+1, j+1)
     if (j > 0) panel_ready_wait(&sy->E[j + 1], 1, sy, info);                      // block (j+1, j): its update with the columns left of block j
     PANEL_STAMP(3 + 6 * j);
-    if (team == 0) gemm_tile_128<true>(Cn, ld, Cn, ld, wp + (int64_t)j * NBI * NBI, 128, 128, sm, 0, 0, 0, nullptr, tid);
+    if (team == 0) gemm_tile_128<true, false, false, false, false, false>(Cn, ld, Cn, ld, wp + (int64_t)j * NBI * NBI, 128, 128, sm, 0, 0, 0, nullptr, tid);
     else gemm_tile_shadow_barriers(128);
     PANEL_STAMP(4 + 6 * j);
     panel_flag_publish(&sy->R[j + 1]);           // rows of strip j+1 left of its diagonal block are final
@@ -908,7 +1017,7 @@ __device__ __forceinline__ void panel_factor_role(double* sm, double* pan, int64
     if (j > 0) panel_ready_wait(&sy->E[j + 1], 2, sy, info);                      // block (j+1, j+1): likewise
     // the updated block goes to memory (its upper triangle is part of the packed matrix's bits) AND, as potf2's LDS image, straight
     // to the factorisation: no wait for the stores, no reload (5 + 1.5 us per diagonal block)
-    if (team == 0) gemm_tile_128<false, false, false, false, true>(Dn, ld, Cn, ld, Cn, ld, 128, sm, 0, 0, 0, nullptr, tid, sm);
+    if (team == 0) gemm_tile_128<false, false, false, false, true, false>(Dn, ld, Cn, ld, Cn, ld, 128, sm, 0, 0, 0, nullptr, tid, sm);
     else { gemm_tile_shadow_barriers(128); __builtin_amdgcn_s_barrier(); }
     __syncthreads();                             // the image is complete for all 8 waves
     PANEL_STAMP(6 + 6 * j);
@@ -936,16 +1045,16 @@ __device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int6
       if (early && j >= 2) {
         const int64_t ke = (int64_t)(j - 1) * NBI;
         panel_ready_wait(&early[j - 2], j - 1, sy, info);   // L(j, 0..j-2) final
-        gemm_tile_128<false>(C, ld, Arow, ld, pan + cj, ld, (int)ke, smem, 0, 0, 0, nullptr, tid);
+        gemm_tile_128<false, false, false, false, false, false>(C, ld, Arow, ld, pan + cj, ld, (int)ke, smem, 0, 0, 0, nullptr, tid);
         panel_flag_wait(&sy->R[j], sy, info);      // (its vmcnt(0) + barrier: the block is reloaded as the next call's C)
-        gemm_tile_128<false>(C, ld, Arow + ke * ld, ld, pan + cj + ke * ld, ld, 128, smem, 0, 0, 0, nullptr, tid);
+        gemm_tile_128<false, false, false, false, false, false>(C, ld, Arow + ke * ld, ld, pan + cj + ke * ld, ld, 128, smem, 0, 0, 0, nullptr, tid);
       } else {
         panel_flag_wait(&sy->R[j], sy, info);      // rows of strip j left of its diagonal block are final
-        gemm_tile_128<false>(C, ld, Arow, ld, pan + cj, ld, (int)cj, smem, 0, 0, 0, nullptr, tid);
+        gemm_tile_128<false, false, false, false, false, false>(C, ld, Arow, ld, pan + cj, ld, (int)cj, smem, 0, 0, 0, nullptr, tid);
       }
     }
     panel_flag_wait(&sy->W[j], sy, info);
-    gemm_tile_128<true>(C, ld, C, ld, wp + (int64_t)j * NBI * NBI, 128, 128, smem, 0, 0, 0, nullptr, tid);
+    gemm_tile_128<true, false, false, false, false, false>(C, ld, C, ld, wp + (int64_t)j * NBI * NBI, 128, 128, smem, 0, 0, 0, nullptr, tid);
     if (progress) panel_count_publish(progress, teams);
   }
   if (s < TPP) {                                   // diagonal strip: the early part of blocks (s, s-1) and (s, s): K = 128 (s-1)
@@ -956,9 +1065,9 @@ __device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int6
     // which its update tile preloads one tile later, second (E_s = 2).  (The other order -- (s, s) needs my own rows only and can run
     // before R_{s-1} -- left the factor role waiting 13 us for E_3 in every panel.)
     panel_flag_wait(&sy->R[s - 1], sy, info);
-    gemm_tile_128<false>(pan + (int64_t)s * 128 + K * ld, ld, Arow, ld, pan + K, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
+    gemm_tile_128<false, false, false, false, false, false>(pan + (int64_t)s * 128 + K * ld, ld, Arow, ld, pan + K, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
     panel_count_publish(&sy->E[s], 1);
-    gemm_tile_128<false>(pan + (int64_t)s * 128 + (int64_t)s * NBI * ld, ld, Arow, ld, Arow, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
+    gemm_tile_128<false, false, false, false, false, false>(pan + (int64_t)s * 128 + (int64_t)s * NBI * ld, ld, Arow, ld, Arow, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
     panel_count_publish(&sy->E[s], 1);
   }
 }
@@ -1017,11 +1126,11 @@ __device__ __forceinline__ void inv512_row_role(double* smem, const double* pan,
     for (int e = tid; e < 128 * 128; e += 256) C[(e & 127) + (int64_t)(e >> 7) * NB] = 0.0;
     if (sy) panel_flag_wait(&sy->W[i], sy, info);        // (its vmcnt(0) + barrier also settle the stores above for the team's loads)
     else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
-    gemm_tile_128<false>(C, NB, T + (int64_t)j * 128 + (int64_t)j * 128 * NB, NB, pan + (int64_t)i * 128 + (int64_t)j * 128 * ld, ld, 128 * (i - j), smem,
+    gemm_tile_128<false, false, false, false, false, false>(C, NB, T + (int64_t)j * 128 + (int64_t)j * 128 * NB, NB, pan + (int64_t)i * 128 + (int64_t)j * 128 * ld, ld, 128 * (i - j), smem,
                          0, 0, 0, nullptr, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    gemm_tile_128<true>(C, NB, C, NB, wp + (int64_t)i * NBI * NBI, 128, 128, smem, 0, 0, 0, nullptr, tid);
+    gemm_tile_128<true, false, false, false, false, false>(C, NB, C, NB, wp + (int64_t)i * NBI * NBI, 128, 128, smem, 0, 0, 0, nullptr, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -1082,7 +1191,7 @@ __device__ __forceinline__ void panel_next_diag_role(double* smem, const double*
   for (int j = 0; j < TPP; ++j) {
     panel_ready_wait(&sy->LA, TPP * (j + 1), sy, info);
     if (stamp && j == TPP - 1 && threadIdx.x == 0) *stamp = __builtin_amdgcn_s_memrealtime();
-    gemm_tile_128<false>(C, ldn, pan + (int64_t)(TPP + tr) * 128 + (int64_t)j * NBI * ld, ld, pan + (int64_t)(TPP + tc) * 128 + (int64_t)j * NBI * ld, ld,
+    gemm_tile_128<false, false, false, false, false, false>(C, ldn, pan + (int64_t)(TPP + tr) * 128 + (int64_t)j * NBI * ld, ld, pan + (int64_t)(TPP + tc) * 128 + (int64_t)j * NBI * ld, ld,
                          128, smem, 0, 0, 0, nullptr, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile is reloaded as the next chunk's C
     __syncthreads();
