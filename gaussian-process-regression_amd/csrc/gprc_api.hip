@@ -474,8 +474,13 @@ int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* 
 // each of 256 CUs: the partially filled last generation of long tiles stays cheap); G >= P degenerates to plain right-looking.  GPRC_SOLVE=right forces that, =left forces G = 1, =<n> G = n.
 // sspart != nullptr: the panel solve that finalises a 128-column block also leaves that block's per-row sum of squares in
 // sspart[block * m_pad + row] (n_pad / 128 blocks): colSums(v * v) without another pass over the chunk.
+// tri_row0 >= 0 (fit()'s gradient, diag(K^-1)): the m_pad rows of vt are rows tri_row0, tri_row0 + 1, ... of the IDENTITY.  Row i of
+// the result, (L^-1 e_{tri_row0 + i})^T, is zero left of column tri_row0 + i, so (a) a panel touches only the rows that start at or
+// left of its last column and (b) a row tile's left-looking pass starts at the tile's first column: n^3 / 3 flops for the whole
+// inverse instead of n^3.  Everything skipped is a product with an exact zero: the same bits as the dense solve
+// (test_fit_gradient_triangular_solve_is_bit_identical); sspart must have been zeroed (rows never reached keep their zeros).
 int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t n_pad, double* vt, int64_t ldv, int64_t m_pad,
-               double* sspart = nullptr) {
+               double* sspart = nullptr, int64_t tri_row0 = -1) {
   hipStream_t s = ctx->stream;
   const int64_t P = n_pad / NB;
   const char* mode = std::getenv("GPRC_SOLVE");
@@ -483,27 +488,35 @@ int solve_rows(gprc_ctx* ctx, const double* packed, const double* winv, int64_t 
   if (mode && std::strcmp(mode, "left") == 0) G = 1;
   else if (mode && std::atoi(mode) > 0) G = std::atoi(mode);  // an explicit group size
   if ((mode && std::strcmp(mode, "right") == 0) || G > P) G = P;
+  auto rows_of = [&](int64_t col_end) {   // rows of the chunk that are not identically zero left of column col_end
+    if (tri_row0 < 0) return m_pad;
+    return std::max<int64_t>(0, std::min<int64_t>(m_pad, pad_up(col_end - tri_row0, 128)));
+  };
   for (int64_t g0 = 0; g0 < P; g0 += G) {
     const int64_t g1 = std::min(P, g0 + G);  // panels [g0, g1)
-    GPRC_TRY(launch_solve_left(s, vt, ldv, m_pad, packed, n_pad, g0, g1 - g0));
+    const int64_t mg = rows_of(g1 * NB);
+    if (mg == 0) continue;
+    GPRC_TRY(launch_solve_left(s, vt, ldv, mg, packed, n_pad, g0, g1 - g0, tri_row0));
     static const bool panel_steps = [] { const char* e = std::getenv("GPRC_SOLVE_PANEL"); return e && std::strcmp(e, "steps") == 0; }();
     for (int64_t p = g0; p < g1; ++p) {
       const int64_t ld = panel_ld(n_pad, p);
       const double* pan = packed + panel_offset(n_pad, p);
+      const int64_t mp = rows_of((p + 1) * NB);
+      if (mp == 0) continue;
       if (!panel_steps) {                   // the four sub-steps of the panel in one launch (GPRC_SOLVE_PANEL=steps: seven launches, same bits)
-        GPRC_TRY(launch_solve_panel_fused(s, vt, ldv, m_pad, packed, n_pad, p, winv, sspart));
+        GPRC_TRY(launch_solve_panel_fused(s, vt, ldv, mp, packed, n_pad, p, winv, sspart, m_pad));
       } else
       for (int j = 0; j < NB / NBI; ++j) {  // inside the panel, left-looking by 128-column blocks (K = 128 j, as factor_subpanel)
         const int64_t cj = p * NB + (int64_t)j * NBI;  // global column
         const double* wblk = winv + (p * (NB / NBI) + j) * NBI * NBI;
         if (j > 0)
-          GPRC_TRY(launch_gemm_nt(s, vt + cj * ldv, ldv, vt + p * NB * ldv, ldv, pan + (int64_t)j * NBI, ld, m_pad, NBI, (int64_t)j * NBI, 0,
+          GPRC_TRY(launch_gemm_nt(s, vt + cj * ldv, ldv, vt + p * NB * ldv, ldv, pan + (int64_t)j * NBI, ld, mp, NBI, (int64_t)j * NBI, 0,
                                   PK_GEMM_INNER));
-        GPRC_TRY(launch_trsm_panel(s, vt + cj * ldv, ldv, m_pad, wblk, sspart ? sspart + (cj / NBI) * m_pad : nullptr));
+        GPRC_TRY(launch_trsm_panel(s, vt + cj * ldv, ldv, mp, wblk, sspart ? sspart + (cj / NBI) * m_pad : nullptr));
       }
       const int64_t right = (g1 - (p + 1)) * NB;  // the rest of the group
       if (right > 0)
-        GPRC_TRY(launch_gemm_nt(s, vt + (p + 1) * NB * ldv, ldv, vt + p * NB * ldv, ldv, pan + NB, ld, m_pad, right, NB, 0, PK_SOLVE_UPDATE));
+        GPRC_TRY(launch_gemm_nt(s, vt + (p + 1) * NB * ldv, ldv, vt + p * NB * ldv, ldv, pan + NB, ld, mp, right, NB, 0, PK_SOLVE_UPDATE));
     }
   }
   return 0;
@@ -950,7 +963,10 @@ int gprc_fit_gradient(gprc_ctx* ctx, int kernel, const double* params, int n_par
   for (int64_t s0 = 0; s0 < n; s0 += rows) {
     const int64_t mcur = std::min<int64_t>(rows, n - s0), m_pad = pad_up(mcur, 128);
     GPRC_TRY(launch_set_identity_rows(s, vt, m_pad, m_pad, n_pad, s0));
-    GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt, m_pad, m_pad, red));
+    // rows s0.. of the identity: the triangular form of the solve (n^3 / 3 over all chunks; GPRC_FITGRAD_DENSE=1: the dense n^3 form)
+    static const bool dense = std::getenv("GPRC_FITGRAD_DENSE") != nullptr;
+    if (!dense) GPRC_HIP(hipMemsetAsync(red, 0, sizeof(double) * (size_t)(m_pad * (n_pad / NBI)), s));
+    GPRC_TRY(solve_rows(ctx, m->packed, m->winv, n_pad, vt, m_pad, m_pad, red, dense ? -1 : s0));
     GPRC_TRY(launch_sum_partials(s, red, n_pad / NBI, m_pad, m_pad, nullptr, kinv.p + s0));  // writes m_pad entries: kinv has n_pad
   }
   GPRC_TRY(launch_deriv_rowsum(s, kernel, params[0], n_params > 1 ? params[1] : 0.0, m->X, d, n, S.p));

@@ -91,7 +91,7 @@ int launch_potf2_inv(hipStream_t s, double* A, int64_t lda, double* winv, int* i
 int launch_panel_fused(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync16);
 // the predict's in-panel solve of panel p in one launch (see solve_panel_fused_kernel)
 int launch_solve_panel_fused(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t p,
-                             const double* winv, double* sspart);
+                             const double* winv, double* sspart, int64_t ss_stride = 0);   // ss_stride: rows per block of sspart (0: m_pad)
 // X[M x 128] := X * W^T for lower-triangular 128x128 W (= inverse of a diagonal block of L)
 int launch_trsm_panel(hipStream_t s, double* X, int64_t ldx, int64_t M, const double* winv, double* ssq = nullptr);
 // C[M x N] -= A[M x K] * B[N x K]^T; lower_diag >= 0: row tile r / col tile c with r + lower_diag < c is skipped
@@ -99,7 +99,9 @@ int launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64
                    int64_t M, int64_t N, int64_t K, int lower, int kind);
 // trailing update of packed panels q_begin, q_begin+q_stride, ... < q_end with factored panel p
 // left-looking predict-solve step: vt[:, j NB:(j+G) NB] -= vt[:, 0:j NB] * L[j NB:(j+G) NB, 0:j NB]^T   (L packed)
-int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t j, int64_t G);
+// tri_row0 >= 0: the rows of vt are rows tri_row0.. of the identity (zero left of their own column): per tile the pass starts there
+int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t j, int64_t G,
+                      int64_t tri_row0 = -1);
 int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t p, int64_t q_begin, int64_t q_end,
                            int64_t q_stride);
 // factor service (one-GPU right-looking sweep): the dependent chain of all panels in one persistent launch (side stream) + per panel

@@ -781,19 +781,31 @@ __global__ __launch_bounds__(256, 2) void trailing_kernel(double* packed, int64_
 // changes is that a C tile is loaded and stored once instead of j times -- the per-tile prologue (C preload + first
 // DMA, ~7 % of a K = 512 tile during which the tile's waves issue no MFMA) is paid once per j NB of K.
 // [kp0, kp1): the source panels of this launch (kp0 = 0, kp1 = j: the whole pass; GPRC_KCHUNK splits it into K-chunks)
+// tri_row0 >= 0 (fit()'s gradient: the rows of vt are rows tri_row0, tri_row0 + 1, ... of the IDENTITY, so row i is zero left of
+// column tri_row0 + i and stays zero there): a tile's pass starts at its first row's column instead of column 0 -- the skipped
+// products are exact zeros, so the bits are those of the full pass -- and a tile whose rows start right of the pass has nothing to do.
 __global__ __launch_bounds__(256, 2) void solve_left_kernel(double* vt, int64_t ldv, const double* packed, int64_t n_pad, int j,
-                                                            int tiles_m, int tiles_n, int group, int kp0, int kp1) {
+                                                            int tiles_m, int tiles_n, int group, int kp0, int kp1, int64_t tri_row0) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const unsigned ntiles = (unsigned)tiles_m * (unsigned)tiles_n;
-  const unsigned id = xcd_remap(blockIdx.x, ntiles);
+  // (the triangular form keeps block id -> tile: a tile's length falls with its row, and XCD-contiguous id ranges would hand one XCD
+  //  all the long tiles and another none -- measured 27 TFLOP/s; round-robin over the XCDs every one gets the same mix)
+  const unsigned id = tri_row0 >= 0 ? blockIdx.x : xcd_remap(blockIdx.x, ntiles);
   const int width = group * tiles_n;
   const int g = id / width, first_m = g * group;
   const int gsize = (tiles_m - first_m < group) ? (tiles_m - first_m) : group;
   const int tr = first_m + (int)(id % width) % gsize;
   const int tc = (int)(id % width) / gsize;
   const int64_t col = (int64_t)j * NB + (int64_t)tc * 128;
-  gemm_tile_128<false, true>(vt + (int64_t)tr * 128 + col * ldv, ldv, vt + (int64_t)tr * 128 + (int64_t)kp0 * NB * ldv, ldv, packed, n_pad,
-                             (kp1 - kp0) * NB, smem, col, 0, kp0 * (NB / 16));
+  int kt_first = kp0 * (NB / 16);
+  const int kt_end = kp1 * (NB / 16);
+  if (tri_row0 >= 0) {
+    const int64_t first_col = tri_row0 + (int64_t)tr * 128;      // a multiple of 128: whole k-tiles
+    if (first_col / 16 > kt_first) kt_first = (int)(first_col / 16);
+    if (kt_first >= kt_end) return;
+  }
+  gemm_tile_128<false, true>(vt + (int64_t)tr * 128 + col * ldv, ldv, vt + (int64_t)tr * 128 + (int64_t)kt_first * 16 * ldv, ldv, packed, n_pad,
+                             (kt_end - kt_first) * 16, smem, col, 0, kt_first);
 }
 
 
@@ -1525,7 +1537,8 @@ static int ensure_gemm_attrs() {
   return 0;
 }
 
-int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t j, int64_t G) {
+int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t j, int64_t G,
+                      int64_t tri_row0) {
   if (j <= 0 || m_pad <= 0 || G <= 0) return 0;
   if (m_pad % 128) { set_error("solve_left: m_pad must be a multiple of 128"); return GPRC_ERR_ARG; }
   if ((j + G) * NB > n_pad) { set_error("solve_left: panel group beyond the factor"); return GPRC_ERR_ARG; }
@@ -1550,13 +1563,18 @@ int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, con
   }
   for (int64_t kp0 = 0; kp0 < j; kp0 += step) {
     const int64_t kp1 = std::min(j, kp0 + step), K = (kp1 - kp0) * NB;
-    ProfScope ps(s, PK_SOLVE_LEFT, 2.0 * (double)m_pad * N * (double)K, 8.0 * (2.0 * m_pad * N + (double)m_pad * K + (double)N * K));
-    if (use256)
+    double fl = 2.0 * (double)m_pad * N * (double)K;
+    if (tri_row0 >= 0) {   // algorithmic work of the triangular form: per 128-row tile only the columns from its first row on
+      fl = 0.0;
+      for (int64_t tr = 0; tr < m_pad / 128; ++tr) fl += 2.0 * 128.0 * N * (double)std::max<int64_t>(0, kp1 * NB - std::max<int64_t>(kp0 * NB, tri_row0 + tr * 128));
+    }
+    ProfScope ps(s, PK_SOLVE_LEFT, fl, 8.0 * (2.0 * m_pad * N + (double)m_pad * K + (double)N * K));
+    if (use256 && tri_row0 < 0)
       hipLaunchKernelGGL(solve_left_kernel256, dim3((unsigned)(tiles / 2)), dim3(512), T2_SMEM_DOUBLES * sizeof(double), s, vt, ldv, packed, n_pad,
                          (int)j, (int)(m_pad / 256), (int)(N / 128), 8, (int)kp0, (int)kp1);
     else
       hipLaunchKernelGGL(solve_left_kernel, dim3((unsigned)tiles), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, vt, ldv, packed, n_pad,
-                         (int)j, (int)(m_pad / 128), (int)(N / 128), 8, (int)kp0, (int)kp1);
+                         (int)j, (int)(m_pad / 128), (int)(N / 128), 8, (int)kp0, (int)kp1, tri_row0);
     GPRC_LAUNCH_CHECK();
   }
   return 0;
@@ -1566,15 +1584,16 @@ int launch_solve_left(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, con
 // vt[:, panel p] := vt[:, panel p] L_pp^-T (in place; everything left of panel p already applied); sspart (may be null):
 // per-row sums of squares of the four finished 128-column blocks at sspart[(4 p + j) * m_pad + row]
 int launch_solve_panel_fused(hipStream_t s, double* vt, int64_t ldv, int64_t m_pad, const double* packed, int64_t n_pad, int64_t p,
-                             const double* winv, double* sspart) {
+                             const double* winv, double* sspart, int64_t ss_stride) {
   if (m_pad <= 0) return 0;
+  if (ss_stride <= 0) ss_stride = m_pad;
   if (m_pad % 128) { set_error("solve_panel_fused: m_pad must be a multiple of 128"); return GPRC_ERR_ARG; }
   GPRC_TRY(ensure_gemm_attrs());
   const double M = (double)m_pad;
   ProfScope ps(s, PK_SOLVE_PANEL, M * 128.0 * 128.0 * TPP + 2.0 * M * 128.0 * 128.0 * (TPP * (TPP - 1) / 2), 8.0 * 2.0 * M * NB);
   const size_t smem = G_SMEM_DOUBLES * sizeof(double);
-  if (sspart) hipLaunchKernelGGL(solve_panel_fused_kernel<true>, dim3((unsigned)(m_pad / 128)), dim3(256), smem, s, vt, ldv, packed, n_pad, (int)p, winv, sspart, m_pad);
-  else hipLaunchKernelGGL(solve_panel_fused_kernel<false>, dim3((unsigned)(m_pad / 128)), dim3(256), smem, s, vt, ldv, packed, n_pad, (int)p, winv, sspart, m_pad);
+  if (sspart) hipLaunchKernelGGL(solve_panel_fused_kernel<true>, dim3((unsigned)(m_pad / 128)), dim3(256), smem, s, vt, ldv, packed, n_pad, (int)p, winv, sspart, ss_stride);
+  else hipLaunchKernelGGL(solve_panel_fused_kernel<false>, dim3((unsigned)(m_pad / 128)), dim3(256), smem, s, vt, ldv, packed, n_pad, (int)p, winv, sspart, ss_stride);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

@@ -163,3 +163,25 @@ def test_kernel_specific_constructors_default_to_fit():
     assert gs.k.gprc_kernel[1][0] == 0.5
     with pytest.raises(ValueError, match="length\\(sigma\\) == nrow\\(X\\)"):
         GPR.linear.new(np.vstack([x, x ** 2]), y, 0.05)                # d = 2: the fitted scalar sigma fails :298, as in R
+
+
+def test_fit_gradient_triangular_solve_is_bit_identical():
+    """dens_deriv's diag(K^-1) (R/fit.R:131: solve(K)) comes from L^-1 computed panel-wise on rows of the identity.  The rows are zero
+    left of their own column, so the solve skips those products (n^3 / 3 instead of n^3 flops); everything skipped is a product
+    with an exact zero, hence the SAME BITS as the dense solve (GPRC_FITGRAD_DENSE=1, in a child process: the switch is read once).
+    n = 3000: six panels, several row chunks (GPRC_CHUNK_BYTES keeps a chunk at 1024 rows) and panel groups."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\nimport gprc_amd\nfrom gprc_amd import dens_deriv\n"
+            "rng = np.random.default_rng(8); X = rng.uniform(-1, 1, (4, 3000)); y = rng.normal(size=3000)\n"
+            "for name, v in (('sqrexp', [0.35]), ('rationalquadratic', [0.4, 1.5])):\n"
+            "    print('GRAD', name, dens_deriv(X, y, name, v).tobytes().hex())\n") % (ROOT,)
+    outs = []
+    for extra in ({}, {"GPRC_FITGRAD_DENSE": "1"}, {"GPRC_CHUNK_BYTES": str(1024 * 3072 * 8)}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("GRAD")])
+    assert len(outs[0]) == 2 and outs[0] == outs[1] == outs[2]

@@ -153,16 +153,19 @@ def test_golden_not_positive_definite(golden):
         GPR(X, y, 0.0, kfun(c["kernel"], c["params"]))               # R/GPRclass.R:149
 
 
+GPC_TOL = 1e-12   # observed on MI355X (tools/measure_gpc_errors.py): <= 8e-15 against the golden set and the oracle; the gate is ~100x that
+
+
 def test_golden_gpc(golden):
     for c in golden.of_type("gpc"):
         X, y, Xs = golden.get(c, "X"), golden.get(c, "y"), golden.get(c, "Xs")
         gc = GPC(X, y, kfun(c["kernel"], c["params"]), c["epsilon"])
         assert gc.iterations == int(golden.get(c, "iters")[0]), c["name"]
-        assert nerr(gc.f_hat, golden.get(c, "f_hat")) <= 1e-9, c["name"]
-        assert nerr([gc.logq], golden.get(c, "logq")) <= 1e-9, c["name"]
-        assert nerr(np.diag(gc.L), golden.get(c, "diagL")) <= 1e-9, c["name"]
+        assert nerr(gc.f_hat, golden.get(c, "f_hat")) <= GPC_TOL, c["name"]
+        assert nerr([gc.logq], golden.get(c, "logq")) <= GPC_TOL, c["name"]
+        assert nerr(np.diag(gc.L), golden.get(c, "diagL")) <= GPC_TOL, c["name"]
         fs, vf = gc.predict_latent(Xs)
-        assert nerr(fs, golden.get(c, "fs_bar")) <= 1e-9 and nerr(vf, golden.get(c, "Vfs")) <= 1e-9, c["name"]
+        assert nerr(fs, golden.get(c, "fs_bar")) <= GPC_TOL and nerr(vf, golden.get(c, "Vfs")) <= GPC_TOL, c["name"]
         assert nerr(gc.predict_class(Xs), golden.get(c, "prob")) <= 1e-7, c["name"]   # QUADPACK on both sides
 
 
@@ -297,11 +300,11 @@ def test_gpc_against_oracle_random():
     oc = orc.gpc_fit(orc.SQREXP, [1.0], X, y, 1e-5, divergence_stop=False)
     gc = GPC(X, y, cov_func(sqrexp, l=1.0), 1e-5, reference_stop=False)
     assert gc.iterations == oc["iters"]
-    assert nerr(gc.f_hat, oc["f_hat"]) <= 1e-9 and abs(gc.logq - oc["logq"]) <= 1e-9 * abs(oc["logq"])
-    assert nerr(gc.L, oc["L"]) <= 1e-9
+    assert nerr(gc.f_hat, oc["f_hat"]) <= GPC_TOL and abs(gc.logq - oc["logq"]) <= GPC_TOL * abs(oc["logq"])
+    assert nerr(gc.L, oc["L"]) <= GPC_TOL
     fs, vf = gc.predict_latent(Xs)
     ofs, ovf = orc.gpc_predict_latent(orc.SQREXP, [1.0], X, y, oc["f_hat"], oc["L"], Xs)
-    assert nerr(fs, ofs) <= 1e-9 and nerr(vf, ovf) <= 1e-9
+    assert nerr(fs, ofs) <= GPC_TOL and nerr(vf, ovf) <= GPC_TOL
     for name in ("X", "k", "y", "f_hat", "L", "logq"):
         with pytest.raises(AttributeError, match="read only"):
             setattr(gc, name, 0)

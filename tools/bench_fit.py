@@ -3,8 +3,9 @@ gradient dens_deriv (R/fit.R:126-139), with the CPU oracle's versions timed besi
 
     python tools/bench_fit.py [n] [d]          -> one JSON line (commit under profiles/)
 
-Algorithmic work: dens = n^3/3 (Cholesky) + n^2 fill; dens_deriv = n^3/3 (Cholesky) + n^3 (rows of L^-T for
-diag(K^-1)) + 2 n^2 derivative evaluations."""
+Algorithmic work: dens = n^3/3 (Cholesky) + n^2 fill; dens_deriv = n^3/3 (Cholesky) + n^3/3 (the triangular inverse L^-1,
+row chunk by row chunk, for diag(K^-1); n^3 before round 3, when the solve ignored the zeros of the identity's rows) + 2 n^2
+derivative evaluations."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -31,6 +32,8 @@ def timed(fn, reps):
 L = nat.lib()
 L.gprc_prof_enable(1); L.gprc_prof_reset()
 t_dens, logp = timed(lambda: g.dens(X, y, 0.1, "rationalquadratic", v), 3)
+prof_dens = {k: r for k, r in nat.prof_summary().items() if r["count"]}
+L.gprc_prof_reset()
 t_grad, grad = timed(lambda: g.dens_deriv(X, y, "rationalquadratic", v), 3)
 prof = {k: r for k, r in nat.prof_summary().items() if r["count"]}
 L.gprc_prof_enable(0)
@@ -50,8 +53,10 @@ print(json.dumps({
     "what": "fit() per-trial calls, rationalquadratic, host pointers (PCIe-inclusive: X, y in; scalars out)",
     "n": n, "d": d,
     "dens_ms": round(t_dens * 1e3, 2), "dens_tflops": round((n ** 3 / 3) / t_dens * 1e-12, 2),
-    "dens_deriv_ms": round(t_grad * 1e3, 2), "dens_deriv_tflops": round((4 * n ** 3 / 3) / t_grad * 1e-12, 2),
+    "dens_deriv_ms": round(t_grad * 1e3, 2), "dens_deriv_tflops": round((2 * n ** 3 / 3) / t_grad * 1e-12, 2),
     "deriv_rowsum_kernel_ms": round(prof["deriv_rowsum"]["ms"] / prof["deriv_rowsum"]["count"], 3) if "deriv_rowsum" in prof else None,
+    "dens_deriv_kernels_ms_per_call": {k: {"launches": r["count"] // 4, "ms": round(r["ms"] / 4, 2), "tflops": round(r["flops"] / r["ms"] * 1e-9, 1) if r["ms"] else None}
+                                       for k, r in prof.items()},
     "small_n": {"n": 51, "d": 1, "dens_ms": round(t_small * 1e3, 3), "cpu_oracle_dens_ms": round(t_small_o * 1e3, 3)},
     "cpu_oracle": {"n": nc, "threads": 1, "dens_ms": round(t_cd * 1e3, 1), "dens_deriv_ms": round(t_cg * 1e3, 1)},
     "parity_at_cpu_sample": {"dens_rel": abs(chk_l - ref_logp) / abs(ref_logp),
