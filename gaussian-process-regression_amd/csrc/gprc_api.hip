@@ -349,6 +349,11 @@ static int64_t want_for(int64_t n_pad) {
   return n_pad < 20480 ? INT64_MAX : 8192;
 }
 
+static bool service_carries_inverse(int64_t n_pad) {
+  static const int forced = [] { const char* e = std::getenv("GPRC_SERVICE_INV"); return e ? std::atoi(e) : -1; }();   // 0 / 1: experiment switch
+  return forced >= 0 ? forced != 0 : n_pad < 20480;   // measured (profiles/r03_experiments.txt): no difference up to 20480 (+0.5 % there without)
+}
+
 // One GROUP of panels [g0, g1) with the FACTOR SERVICE (kernels_chol.hip): the group's columns have received every earlier panel
 // (left-looking pass, or g0 = 0); inside the group the sweep is right-looking with the whole dependent chain -- diagonal blocks, the
 // strips around them, the rows of the next diagonal block and that block's update -- in ONE persistent 21-workgroup launch on a side
@@ -359,9 +364,16 @@ int factor_group_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* w
                          void* trace, int launches) {
   hipStream_t s = ctx->stream, side = ctx->side_stream;
   GPRC_TRY(stream_after(ctx, side, s));                       // everything the group's first panel needs precedes the service
-  GPRC_TRY(launch_panel_service(side, packed, n_pad, winv, info_dev, sync, trace, inv, g0, g1));
+  // The explicit inverses ride in the service (four more resident workgroups, off the chain) below n_pad = 20480, where the whole
+  // matrix is one group; in the grouped schedule beyond, one launch after the sweep computes them (factor_all_async) and the four
+  // CUs go to the update.
+  GPRC_TRY(launch_panel_service(side, packed, n_pad, winv, info_dev, sync, trace, service_carries_inverse(n_pad) ? inv : nullptr, g0, g1));
   GPRC_TRY(launch_service_gate(s, n_pad, info_dev, sync, launches));   // nothing that waits on the service starts before the service is resident
   GPRC_TRY(launch_panel_strips(s, packed, n_pad, g0, winv, info_dev, sync, trace));        // the later panels' strips ride in the update kernels
+  // (Round 3 measured a batched form of this loop -- panel s applied at once only to the next B + 1 panels, the batch's B panels
+  //  to everything further in ONE K = 512 B pass, bit-identical -- and it was SLOWER at every size: n = 16384 29.9 -> 31.6 / 30.9 /
+  //  30.6 ms for B = 2 / 4 / 8, because the chain idles behind the long pass and the near launches are small and ragged.
+  //  profiles/r03_experiments.txt; removed.)
   for (int64_t p = g0; p + 1 < g1; ++p) GPRC_TRY(launch_trailing_service(s, packed, n_pad, p, winv, info_dev, sync, trace, g1));
   GPRC_TRY(stream_after(ctx, s, side));
   return 0;
@@ -418,7 +430,7 @@ int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv,
       }
       g0 = g1;
     }
-    return (inv && !service) ? launch_inv512(s, packed, n_pad, winv, inv, 0, P) : 0;
+    return (inv && !(service && service_carries_inverse(n_pad))) ? launch_inv512(s, packed, n_pad, winv, inv, 0, P) : 0;
   };
   const int rc = sweep();
   if (rc != 0 && service) {

@@ -1,7 +1,8 @@
 """gprc_dev_factor_all alone (packed sqexp kernel matrix resident, refilled by a device copy each repetition) under the schedule the
 environment selects: milliseconds and TFLOP/s (n^3/3) per size.
     python tools/factor_bench.py 8192 16384 24576            # default schedule
-    GPRC_SERVICE=0 python tools/factor_bench.py ...   # grouped left-looking, one fused launch per panel"""
+    GPRC_SERVICE=0 python tools/factor_bench.py ...   # grouped left-looking, one fused launch per panel
+    GPRC_BENCH_INV=1 ...                              # also the explicit diagonal-block inverses the vector solves need (what a fit asks for)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -22,11 +23,12 @@ for n in [int(a) for a in sys.argv[1:]] or [8192, 16384]:
         nat.check(L.gprc_dev_fill_panel(ctx.handle, 3, pp, npar, X.data_ptr(), 8, n, g.n_pad, 0.1, K.data_ptr(), p))
     torch.cuda.synchronize()
     a = torch.empty_like(K); w = torch.zeros(g.winv_size, dtype=torch.float64, device="cuda"); info = torch.zeros(4, dtype=torch.int32, device="cuda")
+    inv = torch.empty(int(L.gprc_solve_inv_size(g.n_pad)), dtype=torch.float64, device="cuda") if os.environ.get("GPRC_BENCH_INV") else None
     best = 1e9
     for rep in range(6):
         a.copy_(K); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr(), None))
+        nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr(), inv.data_ptr() if inv is not None else None))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if rep: best = min(best, dt)
