@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <utility>
 
 #include "gprc_internal.h"
 
@@ -33,8 +34,8 @@ constexpr int PB = 128;
 // ------------------------------------------------------------------------------------------------
 // Blocked diagonal-block kernel (default): the same factor + inverse, 16 columns at a time.
 // The 128 x 128 block lives in LDS (leading dimension 144: MFMA operand reads conflict-free).  Per 16-column step:
-//   A  wave 0 factors the 16 x 16 diagonal sub-block and inverts it with the register-resident scalar sweep above
-//      (16 sequential pivots; operands exchanged between lanes by ds_bpermute, no LDS memory round trip; sqrt /
+//   A  wave 0 factors the 16 x 16 diagonal sub-block and inverts it with a register-resident scalar sweep (diag16:
+//      16 sequential pivots, a matrix row per lane, operands exchanged inside the 16-lane row by DPP row_newbcast; sqrt /
 //      reciprocal from a Newton-refined v_rsq_f64 -- ~60 dependent cycles instead of the ~600 of the library
 //      sqrt + division);
 //   B  panel rows below: X_I = A_I * Wd^T, and row s of the inverse: X_sJ = Wd * Y_sJ   (4 MFMAs per 16x16 block);
@@ -61,70 +62,95 @@ __device__ __forceinline__ void sqrt_rsqrt(double d, double& root, double& rinv)
   rinv = r;
 }
 
-// Phase A: one wave (64 lanes) factors the 16x16 block at D (LDS, ld BLD) in place (lower), writes its inverse
-// dense to Wd[16][16] (column-major), transposed-strict-lower into D's upper triangle and the diagonal to wdiag.
-// Lane (i = lane & 15, ty = lane >> 4) holds row i, columns ty + 4k (k = 0..3), in registers.  Column j = 4 kb + jj:
-// every lane needs the pivot, its own row's column-j entry and "line[c]" for its four columns c (c < j: row j of the
-// running inverse; c >= j: column j at row c).  All of them come straight out of other lanes' registers with
-// ds_bpermute (__shfl) -- six 64-bit shuffles issued back to back, one LDS-crossbar latency per column.  (Publishing
-// the line through LDS memory instead cost three dependent LDS round trips per column: 800 cycles against ~300.)
+// Phase A: one wave factors the 16x16 block at D (LDS, ld BLD; lower triangle valid) in place, writes its inverse dense to
+// Wd[16][16] (column-major), transposed-strict-lower into D's upper triangle and the diagonal to wdiag.
+//
+// Outer-product Cholesky with the rank-1 update on the matrix core.  The wave holds the full SYMMETRIC working block A and a
+// unit-lower-triangular V (Gauss-Jordan on [A | I]: W = diag(rinv) V at the end) in the accumulator layout of
+// v_mfma_f64_16x16x4: lane (q = lane >> 4, r = lane & 15), register rr <-> element (x = q + 4 rr, y = r).  Row J of either matrix
+// is then ONE register (rr = J / 4) of ONE 16-lane row (q = J % 4), indexed by the lane -- exactly the shape of an MFMA operand
+// in k-slot q.  Pivot J:
+//   u = row J of A (= column J: the block stays bitwise symmetric, l_x l_y and l_y l_x are the same product)
+//   d = u[J] (DPP row_newbcast inside the 16-lane row), rinv = 1/sqrt(d) (v_rsq_f64 + two Newton steps)
+//   l = u rinv below the diagonal, 0 elsewhere and in the other three lane rows;  m = -l rinv
+//   A -= l l^T      one MFMA: both operands are l, k-slot J % 4, the other slots zero
+//   V += m v_J^T    one MFMA: v_J = row J of V (V starts as I, so column J receives m and V[J][J] stays 1)
+// The dependent chain of a column is DPP mov -> rsqrt -> one multiply -> one MFMA (~200 cycles: tools/microbench/dp_latency.hip has
+// the instruction latencies), all 64 lanes work, and a pivot is ~35 instructions.  (An f64 MFMA runs on the SIMD's double-precision
+// lanes: no VALU instruction of the wave issues beside it, so the second MFMA and the column's stores add to the chain rather than
+// hide behind it -- ~400 cycles per pivot measured.)  (Round 2's sweep kept a
+// row per lane quadruple and exchanged six operands per pivot by ds_bpermute: ~85 instructions and ~600 cycles per pivot, 3.7 us per
+// sweep; a row-per-lane form with v_fmac_f64_dpp -- DPP on 64-bit operands issues at ~13 cycles -- reached 3.3 us.)
+// No exec-masked branch and no store inside the sweep: a column's entries of L stay in a register of the lane row that computed
+// them, a non-positive pivot is only noted for one atomic after the sweep.
+template <int SRC>
+__device__ __forceinline__ double row_bcast(double v) {   // lane SRC's v, in every lane of the same 16-lane row
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + SRC, 0xf, 0xf, true);   // DPP_ROW_NEWBCAST0 + SRC
+}
+
+template <int J>
+__device__ __forceinline__ void diag16_pivot(double4_t& A, double4_t& V, double (&rinvs)[4], double (&lcol)[4], unsigned& bad, int q, int r) {
+  constexpr int QJ = J & 3, RJ = J >> 2;
+  const bool inrow = q == QJ;
+  const bool below = inrow && r > J;
+  // ---- the chain (a wave issues in order: the sched_barriers make the program order the schedule)
+  const double u = A[RJ];                             // row J of the working block (lane row QJ)
+  const double d = row_bcast<J>(u);                   // the pivot
+  double rinv = __builtin_amdgcn_rsq(d);              // sqrt_rsqrt's rinv: v_rsq_f64 + two Newton steps
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double e = fma(-(d * rinv), rinv, 1.0);
+    rinv = fma(0.5 * rinv, e, rinv);
+  }
+  const double t = u * rinv;
+  const double lv = below ? t : 0.0;                  // column J of L below the diagonal; zero in the other k-slots
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (J < 15) A = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, lv, A, 0, 0, 1);   // A -= l l^T
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- behind the chain's MFMA
+  if constexpr (J < 15) {
+    const double mv = below ? -(t * rinv) : 0.0;
+    const double vrow = inrow ? V[RJ] : 0.0;                                   // row J of V
+    V = __builtin_amdgcn_mfma_f64_16x16x4f64(mv, vrow, V, 0, 0, 0);            // V += m v_J^T
+  }
+  lcol[RJ] = inrow ? lv : lcol[RJ];                   // column J of L below the diagonal: stored after the sweep by lane row QJ
+  rinvs[RJ] = inrow ? rinv : rinvs[RJ];               // rows x = q + 4 rr of this lane: their pivots are seen by lane row q
+  bad |= ((__builtin_amdgcn_fcmp(d, 0.0, 2 /* ogt */) >> (16 * QJ)) & 1ull) ? 0u : (1u << J);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int... J>
+__device__ __forceinline__ void diag16_sweep(double4_t& A, double4_t& V, double (&rinvs)[4], double (&lcol)[4], unsigned& bad, int q, int r,
+                                             std::integer_sequence<int, J...>) {
+  (diag16_pivot<J>(A, V, rinvs, lcol, bad, q, r), ...);
+}
+
 __device__ __forceinline__ void diag16(double* D, double* Wd, double* wdiag, int* info, int col) {
-  const int l = threadIdx.x & 63, i = l & 15, ty = l >> 4;
-  double reg[4];
-  double my_rinv = 1.0;
+  const int l = threadIdx.x & 63, r = l & 15, q = l >> 4;
+  double4_t A, V;
+  double rinvs[4] = {1.0, 1.0, 1.0, 1.0}, lcol[4] = {0.0, 0.0, 0.0, 0.0};
+  unsigned bad = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = ty + 4 * k;
-    reg[k] = (c <= i) ? D[i + c * BLD] : 0.0;
+  for (int rr = 0; rr < 4; ++rr) {
+    const int x = q + 4 * rr;
+    A[rr] = (x >= r) ? D[x + r * BLD] : D[r + x * BLD];   // the upper triangle mirrors the lower one
+    V[rr] = (x == r) ? 1.0 : 0.0;
   }
-  // The dependent chain of one column is pivot -> rsqrt -> multiplier -> rank-1 update -> next pivot.  The pivot comes out
-  // of its lane with two v_readlane (a compile-time lane: no LDS crossbar round trip in front of the rsqrt); the other five
-  // operands travel by ds_bpermute and have landed by the time the Newton steps are through.  Nothing is stored inside
-  // the loop: a lane's four column entries of L are kept (lsave) and written after the sweep, and the column's own
-  // register is switched to the inverse entry with selects -- no exec-masked branches on the chain.
-  double lsave[4] = {0.0, 0.0, 0.0, 0.0};
+  diag16_sweep(A, V, rinvs, lcol, bad, q, r, std::make_integer_sequence<int, 16>{});
+  if (bad != 0 && l == 0) atomicCAS(info, 0, col + __builtin_ctz(bad) + 1);  // LAPACK info: first non-PD leading minor
 #pragma unroll
-  for (int kb = 0; kb < 4; ++kb) {
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int j = kb * 4 + jj;
-      const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(reg[kb]), jj * 16 + j),
-                                        __builtin_amdgcn_readlane(__double2loint(reg[kb]), jj * 16 + j));  // pivot: row j, held by ty == jj
-      const double wij = __shfl(reg[kb], jj * 16 + i, 64);  // column j at this lane's row
-      double lv[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = ty + 4 * k;
-        if (k < kb) lv[k] = __shfl(reg[k], ty * 16 + j, 64);          // c < j: inverse row j
-        else if (k > kb) lv[k] = __shfl(reg[kb], jj * 16 + c, 64);    // c > j: column j at row c
-        else lv[k] = __shfl(reg[kb], (ty < jj) ? ty * 16 + j : jj * 16 + c, 64);
-      }
-      if (!(d > 0.0) && l == 0) atomicCAS(info, 0, col + j + 1);  // LAPACK info: first non-PD leading minor
+  for (int rr = 0; rr < 4; ++rr) {
+    const int x = q + 4 * rr;                        // W[x][r] = rinv_x V[x][r]
+    if (r == x) {                                    // the pivot of row x is still where it was read (later updates add l_x l_y with l_x = 0)
       double ljj, rinv;
-      sqrt_rsqrt(d, ljj, rinv);
-      const bool below = i > j;
-      const double lij = below ? wij * rinv : 0.0;
-      const double mult = -lij * rinv;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) reg[k] = fma(mult, lv[k], reg[k]);
-      const bool mine = ty == jj;                       // this lane holds column j of row i
-      lsave[kb] = mine ? (below ? lij : ljj) : lsave[kb];
-      reg[kb] = (mine && below) ? mult : ((mine && i == j) ? 1.0 : reg[kb]);
-      my_rinv = (i == j) ? rinv : my_rinv;
+      sqrt_rsqrt(A[rr], ljj, rinv);
+      D[x + x * BLD] = ljj;
     }
-  }
-#pragma unroll
-  for (int kb = 0; kb < 4; ++kb) {
-    const int j = kb * 4 + ty;
-    if (i >= j) D[i + j * BLD] = lsave[kb];             // L: the column entries at and below the diagonal
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = ty + 4 * k;
-    const double w = (c <= i) ? reg[k] * my_rinv : 0.0;
-    Wd[i + c * 16] = w;
-    if (c < i) D[c + i * BLD] = w;  // strict lower part of the inverse, transposed into the upper triangle
-    if (c == i) wdiag[i] = w;
+    if (r > x) D[r + x * BLD] = lcol[rr];            // column x of L: lane row q = x % 4 kept it
+    const double w = (r <= x) ? V[rr] * rinvs[rr] : 0.0;
+    Wd[x + r * 16] = w;
+    if (r < x) D[r + x * BLD] = w;                    // strict lower part of the inverse, transposed into the upper triangle
+    if (r == x) wdiag[x] = w;
   }
 }
 
