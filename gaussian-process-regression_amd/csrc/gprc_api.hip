@@ -374,7 +374,14 @@ int factor_group_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* w
   //  to everything further in ONE K = 512 B pass, bit-identical -- and it was SLOWER at every size: n = 16384 29.9 -> 31.6 / 30.9 /
   //  30.6 ms for B = 2 / 4 / 8, because the chain idles behind the long pass and the near launches are small and ragged.
   //  profiles/r03_experiments.txt; removed.)
-  for (int64_t p = g0; p + 1 < g1; ++p) GPRC_TRY(launch_trailing_service(s, packed, n_pad, p, winv, info_dev, sync, trace, g1));
+  // ... in ONE persistent launch for the whole group (trailing_sweep_kernel: no partly filled last generation of tiles and no drained
+  // GPU at every panel boundary; n = 8192 / 16384: see profiles/r03_factor_schedules.txt).  GPRC_SWEEP=0: one launch per panel.
+  static const bool per_panel = [] { const char* e = std::getenv("GPRC_SWEEP"); return e && std::atoi(e) == 0; }();
+  if (per_panel) {
+    for (int64_t p = g0; p + 1 < g1; ++p) GPRC_TRY(launch_trailing_service(s, packed, n_pad, p, winv, info_dev, sync, trace, g1));
+  } else {
+    GPRC_TRY(launch_trailing_sweep(s, packed, n_pad, g0, g1, winv, info_dev, sync, trace, service_workgroups(service_carries_inverse(n_pad) && inv)));
+  }
   GPRC_TRY(stream_after(ctx, s, side));
   return 0;
 }

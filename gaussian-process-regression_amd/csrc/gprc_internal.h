@@ -114,6 +114,9 @@ int launch_inv512(hipStream_t s, const double* packed, int64_t n_pad, const doub
 int launch_service_gate(hipStream_t s, int64_t n_pad, int* info_dev, void* sync, int launches);
 int launch_panel_strips(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync, void* trace);
 int launch_trailing_service(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync, void* trace, int64_t q_end);
+int launch_trailing_sweep(hipStream_t s, double* packed, int64_t n_pad, int64_t g0, int64_t g1, double* winv, int* info_dev, void* sync, void* trace,
+                          int service_wgs);
+int service_workgroups(bool with_inverse);
 
 // ---- launchers (kernels_vec.hip) ---------------------------------------------------------------
 int launch_trailing_left(hipStream_t s, double* packed, int64_t n_pad, int64_t q_begin, int64_t q_end);

@@ -947,10 +947,15 @@ __global__ __launch_bounds__(256, 2) void trailing_range_kernel(double* packed, 
 // loads, agent acquire fence + vmcnt(0), workgroup barrier, plain / LDS-DMA loads).
 // ------------------------------------------------------------------------------------------------
 struct PanelSync { int ticket; int failed; int W[4]; int E[4]; int R[4]; int LA; int pad; };   // 16 ints, zeroed before the launch
+static_assert(TPP <= 4, "PanelSync holds four flags of each kind and LA four 8-bit fields: the factor service is written for NB = 4 x 128");
 // Bound of every device-side dependency wait: WALL time (s_memrealtime, 100 MHz), not a poll count -- a busy, shared GPU slows the
 // polls down but must not shorten the patience.  Legitimate waits are below 10 ms (one trailing update at n <= 24576).
 constexpr unsigned long long WAIT_LIMIT_TICKS = 400000000ULL;   // 4 s
-// (factor service only -- LA: finished sub-steps of the four look-ahead strips, 16 when rows [NB, 2 NB) of the panel are final;
+// (factor service only -- LA: the look-ahead strips' finished blocks, one 8-bit count per 128-column sub-step j (a strip adds
+//  1 << 8 j after block (s, j)): field j = TPP when all four strips have finished sub-step j.  A single sum over the sub-steps --
+//  the round-2 form -- reads "4 (j + 1)" also when one strip is a sub-step ahead and another one behind, which happens as soon as
+//  the service's workgroups do not start together (another context's kernels on the GPU): profiles/r03_la_counter_race.txt.
+//  A strip goes through its blocks in order, so field TPP - 1 = TPP -- LA >= TPP << 24 -- means rows [NB, 2 NB) are final;
 //  E[0], E[1]: blocks (s, j <= s-2) the diagonal strips s = 2, 3 have finished)
 
 __device__ __forceinline__ void panel_flag_wait(int* flag, PanelSync* sy, int* info) {   // the whole workgroup calls it
@@ -995,6 +1000,28 @@ __device__ __forceinline__ void panel_ready_wait(int* ctr, int need, PanelSync* 
     int spins = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 255) != 0) continue;
+      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) {   // bounded in wall time (see panel_flag_wait)
+        __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
+// waits until the 8-bit field at `shift` of *ctr has reached `need` (the look-ahead strips' per-sub-step counts in LA)
+__device__ __forceinline__ void panel_field_wait(int* ctr, int shift, int need, PanelSync* sy, int* info) {   // the whole workgroup calls it
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (((__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> shift) & 0xff) < need) {
       __builtin_amdgcn_s_sleep(2);
       if ((++spins & 255) != 0) continue;
       if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
@@ -1070,8 +1097,9 @@ __device__ __forceinline__ void panel_factor_role(double* sm, double* pan, int64
 // release.  early (may be null; factor service: the progress counters of the diagonal strips 2 and 3, early[0] / early[1]): an
 // ordinary strip then applies the k-chunks 0..j-2 of the update of block (s, j) as soon as L(j, 0..j-2) is final -- long before R_j --
 // and only the last chunk (columns of block j-1) after R_j: the same products in the same order, continued through memory.
+// progress_shift: the count of block (s, j) goes to the 8-bit field j of *progress (teams << progress_shift j; 0: one plain sum).
 __device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int64_t ld, double* wp, int* info, PanelSync* sy, int s, int tid,
-                                                 int* progress = nullptr, int teams = 1, int* early = nullptr) {
+                                                 int* progress = nullptr, int teams = 1, int* early = nullptr, int progress_shift = 0) {
   if (s < 2) return;
   const double* Arow = pan + (int64_t)s * 128;     // my 128 rows of the panel
   const int jlast = s < TPP ? s - 2 : TPP - 1;     // a diagonal strip solves blocks (s, 0..s-2) itself
@@ -1093,7 +1121,7 @@ __device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int6
     }
     panel_flag_wait(&sy->W[j], sy, info);
     gemm_tile_128<true, false, false, false, false, false>(C, ld, C, ld, wp + (int64_t)j * NBI * NBI, 128, 128, smem, 0, 0, 0, nullptr, tid);
-    if (progress) panel_count_publish(progress, teams);
+    if (progress) panel_count_publish(progress, teams << (progress_shift * j));
   }
   if (s < TPP) {                                   // diagonal strip: the early part of blocks (s, s-1) and (s, s): K = 128 (s-1)
     const int64_t K = (int64_t)(s - 1) * NBI;
@@ -1194,7 +1222,7 @@ __global__ __launch_bounds__(256, 2) void inv512_kernel(const double* packed, in
 //   roles 3..6    LOOK-AHEAD strips 4..7: the rows of panel p that are the rows of the NEXT diagonal block; after every finished
 //                 block (s, j) they count themselves into LA
 //   roles 7..16   the ten lower tiles of the next diagonal block: as soon as the look-ahead strips have finished sub-step j
-//                 (LA >= 4 (j + 1)), D(a, b) -= L(4+a, j) L(4+b, j)^T -- the K = 512 update of that tile in its four k-chunks, in
+//                 (field j of LA = 4), D(a, b) -= L(4+a, j) L(4+b, j)^T -- the K = 512 update of that tile in its four k-chunks, in
 //                 order, continuing one accumulator chain through memory -- and after chunk 3 they count themselves into
 //                 ready[p + 1], on which roles 0..2 start panel p + 1.
 //   roles 17..20  (when the caller wants it) the explicit inverse of the panel's diagonal block for the vector solves, one block
@@ -1206,7 +1234,7 @@ __global__ __launch_bounds__(256, 2) void inv512_kernel(const double* packed, in
 // p + 1, which wait on the service's W / R flags.  That kernel is tied in by counters: its tiles of the next panel's rows 4..7 count
 // into ready_la[p + 1] (the look-ahead strips of panel p + 1 wait for 16), its tiles of the diagonal block after the next count into
 // ready_d2[p + 2] (roles 7..16 wait for 10 before they add panel p + 1's part: k ascending, as in the launch-per-panel form), and its
-// tiles of the next panel's column wait for LA = 16 of panel p (their B operand is the look-ahead strips' result).  Same tiles, same
+// tiles of the next panel's column wait for the last field of LA of panel p (their B operand is the look-ahead strips' result).  Same tiles, same
 // k order: bit-identical.
 // No deadlock: main-stream kernels of panel p wait only on service flags of panel p; the service waits, for panel p, only on the
 // update of panel p - 1, which waits only on service flags of panel p - 1; and nothing that waits on the service is launched before
@@ -1227,7 +1255,7 @@ __device__ __forceinline__ void panel_next_diag_role(double* smem, const double*
   const int tc = idx - tr * (tr + 1) / 2;
   double* C = Dn + (int64_t)tr * 128 + (int64_t)tc * 128 * ldn;
   for (int j = 0; j < TPP; ++j) {
-    panel_ready_wait(&sy->LA, TPP * (j + 1), sy, info);
+    panel_field_wait(&sy->LA, 8 * j, TPP, sy, info);   // all four look-ahead strips have finished sub-step j
     if (stamp && j == TPP - 1 && threadIdx.x == 0) *stamp = __builtin_amdgcn_s_memrealtime();
     gemm_tile_128<false, false, false, false, false, false>(C, ldn, pan + (int64_t)(TPP + tr) * 128 + (int64_t)j * NBI * ld, ld, pan + (int64_t)(TPP + tc) * 128 + (int64_t)j * NBI * ld, ld,
                          128, smem, 0, 0, 0, nullptr, tid);
@@ -1270,7 +1298,7 @@ __global__ __launch_bounds__(512) void panel_service_kernel(double* packed, int6
       if (role < SERVICE_D0) {
         if (p > p_begin) panel_ready_wait(&ready[P + p], PANEL_LA_TILES, sy, info);
         if (role == SERVICE_LA0) SERVICE_STAMP(p, 2);
-        panel_strip_role(sm, pan, ld, wp, info, sy, TPP + (role - SERVICE_LA0), tid, &sy->LA, 1, sy->E);
+        panel_strip_role(sm, pan, ld, wp, info, sy, TPP + (role - SERVICE_LA0), tid, &sy->LA, 1, sy->E, 8);
         if (role == SERVICE_LA0) SERVICE_STAMP(p, 3);
       } else {
         if (p > p_begin) panel_ready_wait(&ready[2 * P + p + 1], PANEL_DIAG_TILES, sy, info);
@@ -1318,7 +1346,7 @@ __global__ __launch_bounds__(256, 2) void panel_strips_kernel(double* packed, in
 //   tickets [0, n_first)                    the tiles of panel p + 1's own column, rows [NB, 2 NB) first: those 16 count into
 //                                           ready_la (the service's look-ahead strips of panel p + 1 wait for them), the others into
 //                                           rowcnt[their 128-row strip]; all of them first wait until the look-ahead strips of
-//                                           panel p are final (sy->LA = 16: their B operand)
+//                                           panel p are final (sy->LA >= TPP << 24: their B operand)
 //   tickets [n_first, n_first + nstrips)    strip 8 + i of panel p + 1: waits for its four tiles (rowcnt = 4), then the strip role on
 //                                           the service's W / R flags of panel p + 1
 //   the rest                                all other tiles (XCD-contiguous ranges), the diagonal block of panel p + 2 first (-> ready_d2)
@@ -1388,7 +1416,7 @@ __global__ __launch_bounds__(256, 2) void trailing_service_kernel(double* packed
     tr = TPP + (local - DIAG) / TPP;
     tc = (local - DIAG) % TPP;
   }
-  if (s == 0) panel_ready_wait(&sy->LA, TPP * TPP, sy, info);
+  if (s == 0) panel_ready_wait(&sy->LA, TPP << (8 * (TPP - 1)), sy, info);
   if (t == 0) SERVICE_STAMP(p, 10);
   const int64_t ldp = panel_ld(n_pad, p), ldq = panel_ld(n_pad, q);
   const double* Lp = packed + panel_offset(n_pad, p) + (int64_t)(q - p) * NB;  // row q*NB of panel p
@@ -1399,6 +1427,249 @@ __global__ __launch_bounds__(256, 2) void trailing_service_kernel(double* packed
   if (t == 0) SERVICE_STAMP(p, 11);
   if (sig_d2 && local == 0) SERVICE_STAMP(p, 12);
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// The caller's-stream work of a whole GROUP of panels under the factor service in ONE persistent launch (round 3).
+//
+// One trailing_service_kernel per panel leaves the GPU partly empty at every launch boundary: the last generation of a launch's
+// tiles is only partly filled (at n = 8192 the updates have 3.9, 3.4, 2.9 ... generations of ~470 co-resident tiles: 25 generations
+// are paid for 20.6), the next launch cannot start one tile before the last one of this launch has finished, and an in-order stream
+// has no way to let them overlap (hipExtAnyOrderLaunch is not honoured on gfx950: tools/microbench/anyorder.hip).  Here the same
+// work items -- panel p's tiles of panel p + 1's column, the ordinary strips of panel p + 1, every other tile of panel p's update,
+// p = p_begin .. p_last - 1 -- are dealt to 2 x (CUs - service workgroups) persistent workgroups by ticket counters, and what the
+// kernel boundary used to order is carried by three kinds of flags:
+//   ver[q][tr][tc]        number of the group's panels tile (tr, tc) of panel q has received: the update with panel p waits for
+//                         p - p_begin and leaves p - p_begin + 1 (the same k order as the launch-per-panel form: identical bits);
+//   stripdone[p][strip]   the ordinary strip (>= 2 TPP) of panel p is final -- an operand of panel p's update (the strips of the
+//                         group's first panel ran in a launch of their own in front of this kernel);
+//   the service's counters and flags as before (LA of panel p for the tiles of panel p + 1's column, rowcnt / ready_la / ready_d2).
+// Order of the tickets: panel by panel; inside a panel the `head` (the column of panel p + 1, then that panel's strips: one counter,
+// sy[p].ticket) before the `rest`, which is split into eight contiguous ranges with a counter each -- a workgroup takes from the
+// range of ITS XCD (HW_REG_XCC_ID) so that an XCD's L2 keeps serving neighbouring tiles' operand strips, and from the other ranges
+// only when its own is used up.  A workgroup looks at panel p + 1 only when every ticket of panel p has been taken.
+// No deadlock: a workgroup holding a ticket waits only for tickets that come earlier in this order -- all of them taken by
+// workgroups that are running -- or for the service, which is resident (service_gate_kernel) and itself waits only for such tickets.
+// Every wait is bounded in wall time; after a timeout (info = GPRC_INFO_WAIT_TIMEOUT) every workgroup leaves at its next look.
+// ------------------------------------------------------------------------------------------------
+#ifdef GPRC_SWEEP_PROF
+__device__ unsigned long long g_sweep_prof[8];   // ticks (100 MHz) summed over workgroups: take, wait, gemm, publish, strip; [5] tiles, [6] strips, [7] kernel
+#define SWEEP_T(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#define SWEEP_ADD(k, a, b) do { if (threadIdx.x == 0) atomicAdd(&g_sweep_prof[k], (b) - (a)); } while (0)
+#else
+#define SWEEP_T(var)
+#define SWEEP_ADD(k, a, b)
+#endif
+struct SweepSync {          // views into the sync block behind PanelSync[P], ready[3 P + 16] and rowcnt[P TPP P]
+  int* stripdone;           // [P][TPP P]
+  int* rest_ticket;         // [P][8]
+  int* ver;                 // [P][TPP P][TPP]
+};
+
+// a ticket of counter ctr, or `limit` when it is used up (one lane; one device-scope round trip -- a counter past its limit is harmless)
+__device__ __forceinline__ int sweep_take(int* ctr, int limit) {
+  const int t = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return t < limit ? t : limit;
+}
+
+// waits until *a >= va, *b >= vb, *c >= vc (null pointers are skipped; the three polls fly together), then one acquire for all.
+// false: somebody's wait has timed out (info = GPRC_INFO_WAIT_TIMEOUT) -- the caller leaves.
+__device__ __forceinline__ bool sweep_wait3(int* a, int va, int* b, int vb, int* c, int vc, int* failed, int* info, int* sh_dead) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+      const int xa = a ? __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : va;
+      const int xb = b ? __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : vb;
+      const int xc = c ? __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : vc;
+      if (xa >= va && xb >= vb && xc >= vc) break;
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 63) != 1) continue;              // at the first miss and every 64th from there
+      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) { *sh_dead = 1; break; }
+      if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) {   // bounded in wall time (see panel_flag_wait)
+        __hip_atomic_store(failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
+        *sh_dead = 1;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  return *sh_dead == 0;
+}
+
+// the item is complete: its flag (a version or a strip's "done"), and (may be null) one count for the service / the strips
+__device__ __forceinline__ void sweep_publish(int* flag, int value, int* ctr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ctr) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+struct SweepItem { int kind, p, s, local, strip, flags; };   // kind 0: tile (s, local) of panel p's update; 1: strip of panel p + 1; -1: nothing left
+constexpr int SWEEP_SIG_D2 = 1, SWEEP_FIRST = 2, SWEEP_LAST = 4;
+
+// One lane's view of the ticket order (see the kernel): which panel it is at, which counter, and that panel's item counts.
+struct SweepCursor {
+  int p, phase;                                    // phase 0: head; 1 + k: the rest range of XCD (xcc + k) & 7
+  int n_first, nstrips, nrest, T1;
+  __device__ void enter(int p_, int P, int64_t n_pad, int q_end) {
+    p = p_; phase = 0;
+    constexpr int DIAG = PANEL_DIAG_TILES;
+    const int T0 = TPP * TPP * (P - p - 1) - TPP * (TPP - 1) / 2;   // lower tiles of panel p + 1
+    n_first = T0 - DIAG;                                            // ... without its diagonal block (the service's)
+    const int ld1 = (int)(panel_ld(n_pad, p + 1) / 128);
+    nstrips = ld1 > 2 * TPP ? ld1 - 2 * TPP : 0;
+    int ntiles = -DIAG;
+    for (int q = p + 1; q < q_end; ++q) ntiles += TPP * TPP * (P - q) - TPP * (TPP - 1) / 2;
+    nrest = ntiles - n_first;
+    T1 = T0 - TPP * TPP;                                            // lower tiles of panel p + 2
+  }
+};
+
+// panels p in [p_begin, p_last): the update of panel p over the targets (p, q_end) (without the next diagonal block) and the
+// ordinary strips of panel p + 1.  The caller makes sure p_last - 1 still has something to do (p_last + 1 < P, p_last < q_end).
+__global__ __launch_bounds__(256, 2) void trailing_sweep_kernel(double* packed, int64_t n_pad, int p_begin, int p_last, int q_end, PanelSync* sy_base,
+                                                                int* ready, int* rowcnt, SweepSync sw, double* winv, int* info,
+                                                                unsigned long long* trace) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ SweepItem sh_item;
+  __shared__ int sh_dead;
+  if (threadIdx.x == 0) sh_dead = 0;
+  const int P = (int)(n_pad / NB);
+  constexpr int DIAG = PANEL_DIAG_TILES;
+  const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);   // HW_REG_XCC_ID[3:0]: speed only (which L2 this CU sits behind)
+  SWEEP_T(tkern0);
+
+  // The next item in ticket order (lane 0; one device-scope atomic in the steady state).  Taking it AHEAD of time -- while the
+  // current tile's stores drain -- was measured slower at every size (n = 8192 6.66 against 6.36 ms, 16384 27.75 against 27.52):
+  // a ticket then sits behind its holder's publish while somebody may already be waiting for it.
+  SweepCursor cur;
+  cur.enter(p_begin, P, n_pad, q_end);
+  auto find_next = [&](SweepItem& it) {
+    it.kind = -1; it.flags = 0; it.s = 0; it.local = 0; it.strip = 0;
+    while (cur.p < p_last) {
+      it.p = cur.p;
+      if (cur.phase == 0) {
+        const int lim = cur.n_first + cur.nstrips;
+        const int t = sweep_take(&sy_base[cur.p].ticket, lim);
+        if (t >= lim) { cur.phase = 1; continue; }
+        if (t == 0) it.flags |= SWEEP_FIRST;
+        if (t < cur.n_first) { it.kind = 0; it.local = DIAG + t; }
+        else { it.kind = 1; it.strip = 2 * TPP + (t - cur.n_first); }
+        return;
+      }
+      if (cur.phase <= 8) {
+        const int x = (xcc + cur.phase - 1) & 7;
+        const int rq = cur.nrest >> 3, rr = cur.nrest & 7;
+        const int cnt = rq + (x < rr ? 1 : 0);
+        const int start = x < rr ? x * (rq + 1) : rr * (rq + 1) + (x - rr) * rq;
+        const int i = cnt > 0 ? sweep_take(sw.rest_ticket + (int64_t)cur.p * 8 + x, cnt) : cnt;
+        if (i >= cnt) { ++cur.phase; continue; }
+        int id = start + i;
+        if (id == cur.nrest - 1) it.flags |= SWEEP_LAST;
+        if (id < cur.T1) { it.kind = 0; it.s = 1; it.local = id; if (id < DIAG) it.flags |= SWEEP_SIG_D2; return; }
+        id -= cur.T1;
+        int s = 2;
+        for (; cur.p + 1 + s < q_end; ++s) {
+          const int tq = TPP * TPP * (P - cur.p - 1 - s) - TPP * (TPP - 1) / 2;
+          if (id < tq) break;
+          id -= tq;
+        }
+        if (cur.p + 1 + s < q_end) { it.kind = 0; it.s = s; it.local = id; return; }
+        continue;
+      }
+      if (cur.p + 1 < p_last) cur.enter(cur.p + 1, P, n_pad, q_end);   // every ticket of this panel has been taken
+      else cur.p = p_last;
+    }
+  };
+
+  SweepItem nxt;
+  for (;;) {
+    SWEEP_T(tk0);
+    if (threadIdx.x == 0) find_next(nxt);
+    __syncthreads();                                  // every wave has left the previous item (its LDS, its view of sh_item)
+    if (threadIdx.x == 0) sh_item = nxt;
+    __syncthreads();
+    const SweepItem it = sh_item;
+    SWEEP_T(tk1);
+    SWEEP_ADD(0, tk0, tk1);
+    if (it.kind < 0) break;
+    const int p = it.p;
+    PanelSync* sy = sy_base + p;
+    if (it.flags & SWEEP_FIRST) SERVICE_STAMP(p, 9);
+    if (it.flags & SWEEP_LAST) SERVICE_STAMP(p, 13);
+    if (it.kind == 0) {
+      // ---- one tile of the update with panel p: target q = p + 1 + s, tile (tr, tc) of that panel
+      const int q = p + 1 + it.s, local = it.local;
+      int tr, tc;
+      if (local < DIAG) {
+        tr = 0;
+        while ((tr + 1) * (tr + 2) / 2 <= local) ++tr;
+        tc = local - tr * (tr + 1) / 2;
+      } else {
+        tr = TPP + (local - DIAG) / TPP;
+        tc = (local - DIAG) % TPP;
+      }
+      const int stage = p - p_begin;                                // versions the tiles of this panel's update wait for
+      const int ra = (q - p) * TPP + tr, rb = (q - p) * TPP + tc;   // the operands' 128-row strips of panel p
+      int* verp = sw.ver + ((int64_t)q * TPP * P + tr) * TPP + tc;
+      // strips TPP .. 2 TPP - 1 are the service's look-ahead strips (LA >= TPP << 24 when all four are final); the others ride in this
+      // kernel, except those of the group's first panel, which ran in a launch of their own in front of it
+      int* sd_p = sw.stripdone + (int64_t)p * TPP * P;
+      int* wa = ra >= 2 * TPP ? (stage > 0 ? sd_p + ra : nullptr) : &sy->LA;
+      int* wb = rb >= 2 * TPP ? (stage > 0 ? sd_p + rb : nullptr) : &sy->LA;
+      if (wb == wa) wb = nullptr;
+      SWEEP_T(tw0);
+      constexpr int LA_FINAL = TPP << (8 * (TPP - 1));
+      if (!sweep_wait3(stage > 0 ? verp : nullptr, stage, wa, wa == &sy->LA ? LA_FINAL : 1, wb, wb == &sy->LA ? LA_FINAL : 1, &sy->failed, info, &sh_dead)) break;
+      SWEEP_T(tw1);
+      const int64_t ldp = panel_ld(n_pad, p), ldq = panel_ld(n_pad, q);
+      const double* Lp = packed + panel_offset(n_pad, p) + (int64_t)(q - p) * NB;   // row q NB of panel p
+      double* Cq = packed + panel_offset(n_pad, q);
+      gemm_tile_128<false>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, Lp + (int64_t)tr * 128, ldp, Lp + (int64_t)tc * 128, ldp, NB, smem);
+      SWEEP_T(tw2);
+      int* ctr = nullptr;
+      if (it.s == 0) ctr = tr < 2 * TPP ? &ready[P + q] : &rowcnt[(int64_t)q * TPP * P + tr];
+      else if (it.flags & SWEEP_SIG_D2) ctr = &ready[2 * P + q];
+      sweep_publish(verp, stage + 1, ctr);
+      SWEEP_T(tw3);
+      SWEEP_ADD(1, tw0, tw1); SWEEP_ADD(2, tw1, tw2); SWEEP_ADD(3, tw2, tw3); SWEEP_ADD(5, 0ull, 1ull);
+      if (it.flags & SWEEP_FIRST) SERVICE_STAMP(p, 11);
+    } else {
+      // ---- an ordinary strip of panel p + 1: its four tiles of this update first, then the strip role on the service's flags
+      const int q = p + 1, strip = it.strip;
+      if (strip == 2 * TPP) SERVICE_STAMP(q, 7);
+      if (!sweep_wait3(&rowcnt[(int64_t)q * TPP * P + strip], TPP, nullptr, 0, nullptr, 0, &sy_base[q].failed, info, &sh_dead)) break;
+      panel_strip_role(smem, packed + panel_offset(n_pad, q), panel_ld(n_pad, q), winv + (int64_t)q * TPP * NBI * NBI, info, sy_base + q, strip, (int)threadIdx.x,
+                       nullptr, 1, sy_base[q].E);
+      sweep_publish(sw.stripdone + (int64_t)q * TPP * P + strip, 1, nullptr);
+      SWEEP_T(ts1);
+      SWEEP_ADD(4, tk1, ts1); SWEEP_ADD(6, 0ull, 1ull);
+      if (strip == 2 * TPP) SERVICE_STAMP(q, 8);
+    }
+  }
+  SWEEP_T(tkern1);
+  SWEEP_ADD(7, tkern0, tkern1);
+}
+#ifdef GPRC_SWEEP_PROF
+}  // namespace
+}  // namespace gprc
+extern "C" __attribute__((visibility("default"))) int gprc_debug_sweep_prof(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gprc::g_sweep_prof), 64) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(gprc::g_sweep_prof), z, 64) != hipSuccess) return -1; }
+  return 0;
+}
+namespace gprc {
+namespace {
+#endif
 
 }  // namespace
 
@@ -1449,7 +1720,11 @@ static int ensure_gemm_attrs();
 
 // flags of every panel | ready, ready_la, ready_d2 (P ints each) + the service's "resident" counter | rowcnt (P x 4 P ints: per panel,
 // per 128-row strip, the tiles of that strip which have received the previous panel)
-size_t panel_service_sync_bytes(int64_t P) { return (size_t)P * sizeof(PanelSync) + (3 * (size_t)P + 16) * sizeof(int) + (size_t)P * TPP * P * sizeof(int); }
+// ... and behind them the persistent sweep's flags (trailing_sweep_kernel): stripdone[P][TPP P], rest_ticket[P][8], ver[P][TPP P][TPP]
+size_t panel_service_sync_bytes(int64_t P) {
+  return (size_t)P * sizeof(PanelSync) + (3 * (size_t)P + 16) * sizeof(int) + (size_t)P * TPP * P * sizeof(int) +
+         ((size_t)P * TPP * P + 8 * (size_t)P + (size_t)P * TPP * P * TPP) * sizeof(int);
+}
 
 // sync: panel_service_sync_bytes(P) bytes of device memory, zeroed by the caller (stream-ordered before this launch)
 int launch_inv512(hipStream_t s, const double* packed, int64_t n_pad, const double* winv, double* inv, int64_t p_begin, int64_t p_end) {
@@ -1460,6 +1735,8 @@ int launch_inv512(hipStream_t s, const double* packed, int64_t n_pad, const doub
   GPRC_LAUNCH_CHECK();
   return 0;
 }
+
+int service_workgroups(bool with_inverse) { return with_inverse ? SERVICE_WGS : SERVICE_INV0; }
 
 int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync, void* trace, double* inv,
                          int64_t p_begin, int64_t p_end) {
@@ -1540,6 +1817,46 @@ int launch_trailing_service(hipStream_t s, double* packed, int64_t n_pad, int64_
   return 0;
 }
 
+// the caller's-stream work of the panels [g0, g1) of a group under the service in ONE persistent launch (trailing_sweep_kernel);
+// service_wgs: workgroups the service keeps resident (they hold a CU each)
+int launch_trailing_sweep(hipStream_t s, double* packed, int64_t n_pad, int64_t g0, int64_t g1, double* winv, int* info_dev, void* sync, void* trace,
+                          int service_wgs) {
+  const int64_t P = n_pad / NB;
+  const int64_t q_end = std::min(g1, P);
+  int64_t p_last = g0;                                              // one past the last panel with something to do (launch_trailing_service's rule)
+  for (int64_t p = g0; p + 1 < g1; ++p)
+    if (!(q_end - p - 1 < 1 || p + 2 >= P)) p_last = p + 1;
+  if (p_last == g0) return 0;
+  GPRC_TRY(ensure_gemm_attrs());
+  double fl = 0.0, by = 0.0;
+  for (int64_t p = g0; p < p_last; ++p) {
+    for (int64_t q = p + 1; q < q_end; ++q) {
+      const double rows = (double)(n_pad - q * NB);
+      const double elems = rows * NB - 0.5 * NB * (double)(NB - 1) - (q == p + 1 ? 0.5 * NB * (double)(NB + 1) : 0.0);
+      fl += 2.0 * elems * NB;
+      by += 8.0 * (2.0 * elems + rows * NB);
+    }
+    const int64_t nstrips = std::max<int64_t>(0, panel_ld(n_pad, p + 1) / 128 - 2 * TPP);
+    for (int j = 0; j < TPP; ++j) fl += nstrips * (2.0 * 128 * NBI * (j * NBI) + 128.0 * NBI * NBI);
+  }
+  ProfScope ps(s, PK_TRAILING, fl, by);
+  PanelSync* sy = reinterpret_cast<PanelSync*>(sync);
+  int* ready = reinterpret_cast<int*>(static_cast<char*>(sync) + (size_t)P * sizeof(PanelSync));
+  int* rowcnt = ready + 3 * P + 16;
+  SweepSync sw;
+  sw.stripdone = rowcnt + P * TPP * P;
+  sw.rest_ticket = sw.stripdone + P * TPP * P;
+  sw.ver = sw.rest_ticket + 8 * P;
+  int dev = 0, cus = 0;
+  GPRC_HIP(hipGetDevice(&dev));
+  GPRC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int wgs = std::max(8, 2 * (cus - service_wgs));            // two per CU the service leaves free: all of them co-resident
+  hipLaunchKernelGGL(trailing_sweep_kernel, dim3((unsigned)wgs), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)g0, (int)p_last, (int)q_end,
+                     sy, ready, rowcnt, sw, winv, info_dev, static_cast<unsigned long long*>(trace));
+  GPRC_LAUNCH_CHECK();
+  return 0;
+}
+
 static int ensure_gemm_attrs() {
   static bool done[MAX_DEVICES] = {};  // per device, as above
   int dev = 0;
@@ -1556,6 +1873,7 @@ static int ensure_gemm_attrs() {
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_strips_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_service_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(inv512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_left_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_range_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
