@@ -474,7 +474,7 @@ def main():
         # comes from the separate rocprofv3 --pmc passes of the same command stored under profiles/ (see the JSON's
         # `source`), per launch and corrected as MI355X_MICROARCH.md prescribes; null when no matching profile.
         traffic, traffic_src = None, None
-        for cand in ("r02_c4_pmc_traffic.json", "r01_c4_pmc_traffic.json"):
+        for cand in ("r03_c4_pmc_traffic.json", "r02_c4_pmc_traffic.json", "r01_c4_pmc_traffic.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 if pm["kernel"] == symbol and pm["workload"] == args.workload and pm["n_gpus"] == world and not args.ntrain and not args.nstar:

@@ -345,3 +345,54 @@ def test_fused_in_panel_predict_solve_is_bit_identical():
         assert r.returncode == 0, r.stderr[-2000:]
         digests[mode] = [ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0]
     assert digests["fused"] == digests["steps"], digests
+
+
+def test_two_contexts_factor_many_times_and_every_word_agrees():
+    """Two host threads, each with its own context and stream, factor again and again at the same time on the one GPU.  Their factor
+    services do not start in step then (a service workgroup needs a whole CU and gets it when the other context's kernels let go
+    of one), which is what exposed the round-2 look-ahead counter -- one sum over the sub-steps of the four look-ahead strips: a
+    strip that started late was read by the next diagonal block's update before it had finished (1 factorisation in ~1000 wrong,
+    profiles/r03_la_counter_race.txt).  400 factorisations per thread, every word of factor and block inverses against the first."""
+    import threading
+    L = nat.lib()
+    errs, done = [], []
+
+    def work(i, n):
+        try:
+            st = torch.cuda.Stream()
+            ctx = nat.Context(0, st.cuda_stream)
+            g = Geometry(n)
+            rng = np.random.default_rng(10 + i)
+            X = torch.from_numpy(np.ascontiguousarray(rng.uniform(-1, 1, (n, 3)))).cuda()
+            par, pp, npar = nat.params_array([0.7 + 0.1 * i])
+            with torch.cuda.stream(st):
+                K = torch.zeros(g.packed_size, dtype=torch.float64, device="cuda")
+                st.synchronize()
+                for p in range(g.P):
+                    nat.check(L.gprc_dev_fill_panel(ctx.handle, 3, pp, npar, X.data_ptr(), 3, n, g.n_pad, 0.1, K.data_ptr(), p))
+                st.synchronize()
+                ref = None
+                for r in range(400):
+                    a = K.clone()
+                    w = torch.zeros(g.winv_size, dtype=torch.float64, device="cuda")
+                    info = torch.zeros(4, dtype=torch.int32, device="cuda")
+                    st.synchronize()
+                    nat.check(L.gprc_dev_factor_all(ctx.handle, a.data_ptr(), g.n_pad, w.data_ptr(), info.data_ptr(), NULL))
+                    st.synchronize()
+                    if int(info[0]) != 0:
+                        errs.append(f"thread {i}: info {int(info[0])} at repetition {r}")
+                        break
+                    if ref is None:
+                        ref = (a.clone(), w.clone())
+                    elif not (torch.equal(a, ref[0]) and torch.equal(w, ref[1])):
+                        errs.append(f"thread {i}: repetition {r} differs from the first")
+                        break
+            ctx.close()
+            done.append(i)
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i, n)) for i, n in enumerate((2600, 4100))]
+    [t.start() for t in ts]
+    [t.join(timeout=300) for t in ts]
+    assert not errs and sorted(done) == [0, 1], errs

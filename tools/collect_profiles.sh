@@ -15,6 +15,6 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write 
 python3 tools/pmc_summary.py $out/pmc_fetch solve_left_kernel trailing_range_kernel "gemm_nt_kernel<5>" trailing_kernel fill_kernel panel_fused_kernel > $out/pmc_fetch_summary.txt
 python3 tools/pmc_summary.py $out/pmc_write solve_left_kernel trailing_range_kernel "gemm_nt_kernel<5>" trailing_kernel fill_kernel panel_fused_kernel > $out/pmc_write_summary.txt
 cat $out/pmc_fetch_summary.txt $out/pmc_write_summary.txt
-python3 tools/make_pmc_traffic.py $out solve_left_kernel 0 > /dev/null; cp profiles/r02_c4_pmc_traffic.json $out/pmc_traffic.json
+python3 tools/make_pmc_traffic.py $out solve_left_kernel 0 > /dev/null; cp profiles/r03_c4_pmc_traffic.json $out/pmc_traffic.json
 rm -f $out/*/*/*kernel_trace.csv $out/pmc_*/*/*counter_collection.csv
 grep "^{" $out/bench_c4.log | cut -c1-400

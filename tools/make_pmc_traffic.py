@@ -1,4 +1,4 @@
-"""Builds profiles/r02_c4_pmc_traffic.json (read by bench.py for roofline.traffic) from the two rocprofv3 --pmc passes of
+"""Builds profiles/r03_c4_pmc_traffic.json (read by bench.py for roofline.traffic) from the two rocprofv3 --pmc passes of
 tools/collect_profiles.sh:  python tools/make_pmc_traffic.py gpurun_out/final <kernel symbol> <algorithmic bytes/launch>
 FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (the counter ticks once per 64 B of a 128-B request);
 both counters are reported in kilobytes (1024 B).  Must run BEFORE collect_profiles.sh deletes the per-dispatch CSVs."""
@@ -22,5 +22,5 @@ json.dump({"kernel": sym, "workload": "c4", "n_gpus": 1, "launches_profiled": n,
            "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B; MI355X_MICROARCH.md, HBM section), WRITE_SIZE as read",
            "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py --steps 1 --warmup 0; tools/collect_profiles.sh"},
-          open("profiles/r02_c4_pmc_traffic.json", "w"), indent=1)
-print(open("profiles/r02_c4_pmc_traffic.json").read())
+          open("profiles/r03_c4_pmc_traffic.json", "w"), indent=1)
+print(open("profiles/r03_c4_pmc_traffic.json").read())
