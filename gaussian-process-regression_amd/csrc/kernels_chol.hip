@@ -361,6 +361,20 @@ __device__ __forceinline__ const double* strip_ktile(const double* B, int64_t ld
   }
 }
 
+// The same place WITHOUT the lane's part: the wave-uniform address of k-slice `wave` of k-tile kt (the lane adds 16 bytes x lane as a
+// 32-bit VGPR offset of the LDS-DMA instruction, whose base is then an SGPR pair: no VALU address arithmetic in the loop).
+template <bool SEG>
+__device__ __forceinline__ const char* strip_ktile_s(const double* B, int64_t ldb, int64_t brow, int kt, int wave, int64_t& ld) {
+  if constexpr (SEG) {
+    const int pp = kt / (NB / 16);
+    ld = panel_ld(ldb, pp);
+    return reinterpret_cast<const char*>(B + panel_offset(ldb, pp) + (brow - (int64_t)pp * NB) + (int64_t)((kt % (NB / 16)) * 16 + wave) * ld);
+  } else {
+    ld = ldb;
+    return reinterpret_cast<const char*>(B + (int64_t)(kt * 16 + wave) * ldb);
+  }
+}
+
 // SSQ (the predict's panel solve only): besides storing the tile, leave in ssq[0..127] the sum of squares of each of the
 // tile's 128 rows over its 128 columns -- these columns of v^T are final after this tile, so colSums(v * v)
 // (R/GPRclass.R:164) is assembled from these per-block partials and the pass that re-read the whole solved chunk is gone.
@@ -372,7 +386,9 @@ __device__ __forceinline__ const double* strip_ktile(const double* B, int64_t ld
 // ILV: the main loop with every non-MFMA instruction in the shadow of an MFMA (below) -- the throughput kernels; false keeps the
 // block-structured loop for the roles of the fused panel / service kernels, which inline this function several times and spill
 // with the larger body (their tiles are short -- K = 128..384 -- and paced by flags, not by the loop).
-template <bool SET, bool SEG = false, bool SEGA = false, bool SSQ = false, bool LDSOUT = false, bool ILV = true>
+// CORE (interleaved loops only): 2 = the loop without VALU instructions (the plain throughput kernels), 1 = the first interleaved loop
+// (kept for the tiles that run beside the factor service -- sweep kernel, trailing_service_kernel: measured, see the loops' comments).
+template <bool SET, bool SEG = false, bool SEGA = false, bool SSQ = false, bool LDSOUT = false, bool ILV = true, int CORE = 2>
 __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                                               int64_t ldb, int K, double* smem, int64_t brow = 0, int64_t arow = 0, int kt0 = 0,
                                               double* ssq = nullptr, int tid = -1, double* lds_out = nullptr) {
@@ -433,8 +449,109 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
 #else
   constexpr bool interleaved = false;
 #endif
-  if constexpr (interleaved) {
-  // ---- Main loop, every non-MFMA instruction in the shadow of an MFMA (round 3) ----------------------------------------------
+  if constexpr (interleaved && CORE == 2) {
+  // ---- Main loop (round 3, second form): no VALU instruction but the MFMAs ------------------------------------------------------
+  // An f64 MFMA executes on the SIMD's double-precision lanes, and a VALU instruction issued behind it -- a 32-bit address add as
+  // much as an FMA -- takes the pipe away from the next MFMA: tools/microbench/mfma_valu_mix.hip measures 64 cycles per MFMA for a
+  // pure stream, +14 with one v_add_u32 behind each MFMA, +18 with two; SALU and LDS instructions cost nothing.  The first
+  // interleaved loop still carried ~20 VALU instructions per k-tile and wave (ISA: 8 v_lshl_add_u64 for the LDS-DMA addresses, 12
+  // v_add_u32 / v_subrev_u32 for the ds_read2 bases) -- ~5 % of the pipe.  Here the loop has none:
+  //   * LDS-DMA with an SGPR base: global_load_lds_dwordx4 v_off, s[base:base+1] -- the k-slice's address is wave-uniform, the lane
+  //     contributes a constant 32-bit offset (16 B x lane); the compiler has no such selection for the builtin, hence inline assembly
+  //     (m0 = the slice's LDS row, set by s_mov in the same statement);
+  //   * operand reads as ds_read_b64 with 16-bit immediate offsets from TWO loop-invariant base registers (one per operand): every
+  //     buffer / k-step / block offset is a constant of the instruction once the loop is unrolled by two k-tiles (ds_read2_b64's 8-bit
+  //     offsets reach 2 KB only, and the compiler paid a v_add_u32 per pair for them);
+  //   * the waits for those reads counted by hand (the compiler does not see assembly loads): the reads of a k-step are issued two
+  //     blocks ahead, eight per block, in order: s_waitcnt lgkmcnt(8) in front of a block leaves exactly the next block's in flight.
+  // Same products, same k order, same accumulators as before: identical bits.
+  const unsigned lane_off = 16u * (unsigned)lane;
+  const unsigned ldsA = (unsigned)(uintptr_t)(lptr_t)(As + srow), ldsB = (unsigned)(uintptr_t)(lptr_t)(Bs + srow);                    // wave-uniform
+  const unsigned aBase = (unsigned)(uintptr_t)(lptr_t)(As + wr * 64 + foff), bBase = (unsigned)(uintptr_t)(lptr_t)(Bs + wc * 64 + foff);  // per lane
+  // next tile to request (k-tile 2): wave-uniform addresses
+  int64_t ldas, ldbs;
+  const char* Asg = strip_ktile_s<SEGA>(A, lda, arow, (SEGA ? kt0 : 0) + 2, wave, ldas);
+  const char* Bsg = strip_ktile_s<SEG>(B, ldb, brow, (SEG ? kt0 : 0) + 2, wave, ldbs);
+#define GPRC_SB __builtin_amdgcn_sched_barrier(0);
+#define GPRC_M(A_, B_, i) acc[(i) >> 2][(i) & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(B_[(i) & 3], A_[(i) >> 2], acc[(i) >> 2][(i) & 3], 0, 0, NEG); GPRC_SB
+#define GPRC_RD(dst, base, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off));
+  // two reads (blocks 2r, 2r+1) of k-step kk in buffer buf
+#define GPRC_RA(buf, kk, r, A_) GPRC_RD(A_[2 * (r)], aBase, ((buf) * G_BUF + (kk) * 4 * G_LDT + (2 * (r)) * 16) * 8) GPRC_RD(A_[2 * (r) + 1], aBase, ((buf) * G_BUF + (kk) * 4 * G_LDT + (2 * (r) + 1) * 16) * 8) GPRC_SB
+#define GPRC_RB(buf, kk, r, B_) GPRC_RD(B_[2 * (r)], bBase, ((buf) * G_BUF + (kk) * 4 * G_LDT + (2 * (r)) * 16) * 8) GPRC_RD(B_[2 * (r) + 1], bBase, ((buf) * G_BUF + (kk) * 4 * G_LDT + (2 * (r) + 1) * 16) * 8) GPRC_SB
+#define GPRC_READY(cnt, A_, B_) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]), "+v"(A_[3]), "+v"(B_[0]), "+v"(B_[1]), "+v"(B_[2]), "+v"(B_[3])); GPRC_SB
+#define GPRC_BLOCK_R(A_, B_, buf, kk, RA_, RB_, cond)                                                               \
+  GPRC_M(A_, B_, 0) GPRC_M(A_, B_, 1) if (cond) { GPRC_RA(buf, kk, 0, RA_) }                                        \
+  GPRC_M(A_, B_, 2) GPRC_M(A_, B_, 3) if (cond) { GPRC_RA(buf, kk, 1, RA_) }                                        \
+  GPRC_M(A_, B_, 4) GPRC_M(A_, B_, 5) if (cond) { GPRC_RB(buf, kk, 0, RB_) }                                        \
+  GPRC_M(A_, B_, 6) GPRC_M(A_, B_, 7) if (cond) { GPRC_RB(buf, kk, 1, RB_) }                                        \
+  GPRC_M(A_, B_, 8) GPRC_M(A_, B_, 9) GPRC_M(A_, B_, 10) GPRC_M(A_, B_, 11) GPRC_M(A_, B_, 12) GPRC_M(A_, B_, 13) GPRC_M(A_, B_, 14) GPRC_M(A_, B_, 15)
+  // one LDS-DMA: k-slice wave + 4 i of the tile at Asg / Bsg into buffer buf (m0 <- the slice's LDS row; one wait state before its use)
+#define GPRC_DMA(i, buf, more2)                                                                                      \
+  if (more2) {                                                                                                      \
+    if ((i) < 4) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(Asg + (int64_t)(4 * (i)) * ldas * 8), "s"(ldsA + (unsigned)(((buf) * G_BUF + 4 * (i) * G_LDT) * 8)) : "memory"); \
+    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(Bsg + (int64_t)(4 * ((i) - 4)) * ldbs * 8), "s"(ldsB + (unsigned)(((buf) * G_BUF + 4 * ((i) - 4) * G_LDT) * 8)) : "memory"); \
+    GPRC_SB                                                                                                         \
+  }
+  // one k-tile in buffer buf (the next one in 1 - buf); more1 / more2: a tile kt+1 / kt+2 exists; kt: this tile's index
+#define GPRC_KTILE(buf, more1, more2)                                                                                \
+  {                                                                                                                 \
+    GPRC_SB                                                                                                         \
+    GPRC_READY(8, a0, b0)                                                                                           \
+    GPRC_BLOCK_R(a0, b0, buf, 2, a2, b2, true)                                                                      \
+    GPRC_READY(8, a1, b1)                                                                                           \
+    GPRC_BLOCK_R(a1, b1, buf, 3, a3, b3, true)                                                                      \
+    GPRC_READY(8, a2, b2)                                                                                           \
+    GPRC_M(a2, b2, 0) GPRC_M(a2, b2, 1) GPRC_M(a2, b2, 2) GPRC_M(a2, b2, 3)                                         \
+    if (more1) {                                                                                                    \
+      /* this wave's reads of buffer buf have returned (lgkmcnt) and its share of tile kt+1 has landed (vmcnt); after the */ \
+      /* barrier that holds for every wave: tile kt+1 may be read and buffer buf overwritten */                     \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                   \
+      __builtin_amdgcn_s_barrier();                                                                                 \
+      GPRC_SB                                                                                                       \
+    }                                                                                                               \
+    GPRC_M(a2, b2, 4) if (more1) { GPRC_RA(1 - (buf), 0, 0, a0) }                                                   \
+    GPRC_M(a2, b2, 5) if (more1) { GPRC_RA(1 - (buf), 0, 1, a0) }                                                   \
+    GPRC_M(a2, b2, 6) if (more1) { GPRC_RB(1 - (buf), 0, 0, b0) }                                                   \
+    GPRC_M(a2, b2, 7) if (more1) { GPRC_RB(1 - (buf), 0, 1, b0) }                                                   \
+    GPRC_M(a2, b2, 8) GPRC_DMA(0, buf, more2) GPRC_M(a2, b2, 9) GPRC_DMA(4, buf, more2) GPRC_M(a2, b2, 10) GPRC_DMA(1, buf, more2) GPRC_M(a2, b2, 11) GPRC_DMA(5, buf, more2) \
+    GPRC_M(a2, b2, 12) GPRC_DMA(2, buf, more2) GPRC_M(a2, b2, 13) GPRC_DMA(6, buf, more2) GPRC_M(a2, b2, 14) GPRC_DMA(3, buf, more2) GPRC_M(a2, b2, 15) GPRC_DMA(7, buf, more2) \
+    if (more2) {   /* the tile after the one just requested: 16 columns on, or the next panel of a packed strip (scalar arithmetic) */ \
+      if constexpr (SEGA) { if (((kt0 + kt + 3) % (NB / 16)) == 0) Asg = strip_ktile_s<true>(A, lda, arow, kt0 + kt + 3, wave, ldas); else Asg += (int64_t)G_KB * ldas * 8; } \
+      else Asg += (int64_t)G_KB * ldas * 8;                                                                         \
+      if constexpr (SEG) { if (((kt0 + kt + 3) % (NB / 16)) == 0) Bsg = strip_ktile_s<true>(B, ldb, brow, kt0 + kt + 3, wave, ldbs); else Bsg += (int64_t)G_KB * ldbs * 8; } \
+      else Bsg += (int64_t)G_KB * ldbs * 8;                                                                         \
+      GPRC_SB                                                                                                       \
+    }                                                                                                               \
+    if (more1) { GPRC_READY(8, a3, b3) } else { GPRC_READY(0, a3, b3) }                                             \
+    GPRC_BLOCK_R(a3, b3, 1 - (buf), 1, a1, b1, more1)                                                               \
+  }
+  {   // KT is even and >= 4: every caller's K is a multiple of 128 (eight k-tiles)
+    int kt = 0;
+    for (; kt + 2 < KT; kt += 2) {
+      GPRC_KTILE(0, true, true)
+      ++kt;
+      GPRC_KTILE(1, true, true)
+      --kt;
+    }
+    GPRC_KTILE(0, true, false)
+    ++kt;
+    GPRC_KTILE(1, false, false)
+  }
+#undef GPRC_KTILE
+#undef GPRC_DMA
+#undef GPRC_BLOCK_R
+#undef GPRC_READY
+#undef GPRC_RA
+#undef GPRC_RB
+#undef GPRC_RD
+#undef GPRC_M
+#undef GPRC_SB
+  } else if constexpr (interleaved) {
+  // ---- Main loop, every non-MFMA instruction in the shadow of an MFMA (round 3, first form) -----------------------------------
+  // (Still ~20 VALU instructions per k-tile and wave.  It stays for the K = 512 tiles of the kernels that run BESIDE the factor
+  //  service: with the VALU-free loop their tiles are a third faster, the memory system correspondingly busier, and the service's
+  //  latency-bound roles -- and with them the whole mid-size factorisation -- slower: n = 12288 13.55 -> 14.66 ms, 16384 27.44 -> 28.27,
+  //  same box, profiles/r03_factor_schedules.txt.)
   // Counters on the shipped loop (profiles/r03_c4_core_counters.txt): the MFMA pipes were busy 91.7 % of the kernel's cycles at
   // 2.37 GHz, and per 64 MFMAs a wave issues 73 other instructions -- 16 ds_read2, 8 LDS-DMA with their m0 / address set-up, the
   // s_waitcnt / s_barrier, loop arithmetic.  In the block-structured loop they sat in CLUMPS between the 16-MFMA blocks: four
@@ -958,13 +1075,22 @@ constexpr unsigned long long WAIT_LIMIT_TICKS = 400000000ULL;   // 4 s
 //  A strip goes through its blocks in order, so field TPP - 1 = TPP -- LA >= TPP << 24 -- means rows [NB, 2 NB) are final;
 //  E[0], E[1]: blocks (s, j <= s-2) the diagonal strips s = 2, 3 have finished)
 
-__device__ __forceinline__ void panel_flag_wait(int* flag, PanelSync* sy, int* info) {   // the whole workgroup calls it
+// relaxed: the caller is throughput work (a strip riding in the sweep kernel), not a role of the chain: it looks at the flag once per
+// microsecond instead of every ~50 ns.  Hundreds of workgroups polling flags and counters at full rate slow every device-scope access
+// down -- the chain's own publishes and polls included (measured with the round-3 tile core, whose faster tiles left the sweep's
+// workgroups waiting longer: ticket atomics 6 -> 16 us, n = 8192 factorisation 6.27 -> 6.71 ms; tools/sweep_prof.py).
+__device__ __forceinline__ void poll_pause(bool relaxed) {
+  if (relaxed) __builtin_amdgcn_s_sleep(32);      // 32 x 64 clocks ~ 0.9 us
+  else __builtin_amdgcn_s_sleep(2);
+}
+
+__device__ __forceinline__ void panel_flag_wait(int* flag, PanelSync* sy, int* info, bool relaxed = false) {   // the whole workgroup calls it
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own stores: its team-mates re-read them after the barrier
   if (threadIdx.x == 0) {
     int spins = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-      __builtin_amdgcn_s_sleep(2);
+      poll_pause(relaxed);
       if ((++spins & 255) != 0) continue;
       // somebody has already given up (e.g. a profiler that serialises dispatches keeps producer and consumer kernels apart): every
       // later wait of the factorisation returns at once instead of running out its own bound
@@ -994,13 +1120,13 @@ __device__ __forceinline__ void panel_flag_publish(int* flag) {               //
   }
 }
 
-__device__ __forceinline__ void panel_ready_wait(int* ctr, int need, PanelSync* sy, int* info) {   // the whole workgroup calls it
+__device__ __forceinline__ void panel_ready_wait(int* ctr, int need, PanelSync* sy, int* info, bool relaxed = false) {   // the whole workgroup calls it
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (threadIdx.x == 0) {
     int spins = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-      __builtin_amdgcn_s_sleep(2);
+      poll_pause(relaxed);
       if ((++spins & 255) != 0) continue;
       if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
       if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) {   // bounded in wall time (see panel_flag_wait)
@@ -1099,7 +1225,7 @@ __device__ __forceinline__ void panel_factor_role(double* sm, double* pan, int64
 // and only the last chunk (columns of block j-1) after R_j: the same products in the same order, continued through memory.
 // progress_shift: the count of block (s, j) goes to the 8-bit field j of *progress (teams << progress_shift j; 0: one plain sum).
 __device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int64_t ld, double* wp, int* info, PanelSync* sy, int s, int tid,
-                                                 int* progress = nullptr, int teams = 1, int* early = nullptr, int progress_shift = 0) {
+                                                 int* progress = nullptr, int teams = 1, int* early = nullptr, int progress_shift = 0, bool relaxed = false) {
   if (s < 2) return;
   const double* Arow = pan + (int64_t)s * 128;     // my 128 rows of the panel
   const int jlast = s < TPP ? s - 2 : TPP - 1;     // a diagonal strip solves blocks (s, 0..s-2) itself
@@ -1110,16 +1236,16 @@ __device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int6
     if (j > 0) {
       if (early && j >= 2) {
         const int64_t ke = (int64_t)(j - 1) * NBI;
-        panel_ready_wait(&early[j - 2], j - 1, sy, info);   // L(j, 0..j-2) final
+        panel_ready_wait(&early[j - 2], j - 1, sy, info, relaxed);   // L(j, 0..j-2) final
         gemm_tile_128<false, false, false, false, false, false>(C, ld, Arow, ld, pan + cj, ld, (int)ke, smem, 0, 0, 0, nullptr, tid);
-        panel_flag_wait(&sy->R[j], sy, info);      // (its vmcnt(0) + barrier: the block is reloaded as the next call's C)
+        panel_flag_wait(&sy->R[j], sy, info, relaxed);      // (its vmcnt(0) + barrier: the block is reloaded as the next call's C)
         gemm_tile_128<false, false, false, false, false, false>(C, ld, Arow + ke * ld, ld, pan + cj + ke * ld, ld, 128, smem, 0, 0, 0, nullptr, tid);
       } else {
-        panel_flag_wait(&sy->R[j], sy, info);      // rows of strip j left of its diagonal block are final
+        panel_flag_wait(&sy->R[j], sy, info, relaxed);      // rows of strip j left of its diagonal block are final
         gemm_tile_128<false, false, false, false, false, false>(C, ld, Arow, ld, pan + cj, ld, (int)cj, smem, 0, 0, 0, nullptr, tid);
       }
     }
-    panel_flag_wait(&sy->W[j], sy, info);
+    panel_flag_wait(&sy->W[j], sy, info, relaxed);
     gemm_tile_128<true, false, false, false, false, false>(C, ld, C, ld, wp + (int64_t)j * NBI * NBI, 128, 128, smem, 0, 0, 0, nullptr, tid);
     if (progress) panel_count_publish(progress, teams << (progress_shift * j));
   }
@@ -1130,7 +1256,7 @@ __device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int6
     // block (s, s-1) first: the factor role's solve tile is the next thing on the chain that needs this strip (E_s = 1); block (s, s),
     // which its update tile preloads one tile later, second (E_s = 2).  (The other order -- (s, s) needs my own rows only and can run
     // before R_{s-1} -- left the factor role waiting 13 us for E_3 in every panel.)
-    panel_flag_wait(&sy->R[s - 1], sy, info);
+    panel_flag_wait(&sy->R[s - 1], sy, info, relaxed);
     gemm_tile_128<false, false, false, false, false, false>(pan + (int64_t)s * 128 + K * ld, ld, Arow, ld, pan + K, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
     panel_count_publish(&sy->E[s], 1);
     gemm_tile_128<false, false, false, false, false, false>(pan + (int64_t)s * 128 + (int64_t)s * NBI * ld, ld, Arow, ld, Arow, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
@@ -1421,7 +1547,7 @@ __global__ __launch_bounds__(256, 2) void trailing_service_kernel(double* packed
   const int64_t ldp = panel_ld(n_pad, p), ldq = panel_ld(n_pad, q);
   const double* Lp = packed + panel_offset(n_pad, p) + (int64_t)(q - p) * NB;  // row q*NB of panel p
   double* Cq = packed + panel_offset(n_pad, q);
-  gemm_tile_128<false>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, Lp + (int64_t)tr * 128, ldp, Lp + (int64_t)tc * 128, ldp, NB, smem);
+  gemm_tile_128<false, false, false, false, false, true, 1>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, Lp + (int64_t)tr * 128, ldp, Lp + (int64_t)tc * 128, ldp, NB, smem);
   if (s == 0) panel_count_publish(tr < 2 * TPP ? &ready[P + q] : &rowcnt[(int64_t)q * TPP * P + tr], 1);
   else if (sig_d2) panel_count_publish(&ready[2 * P + q], 1);
   if (t == 0) SERVICE_STAMP(p, 11);
@@ -1484,7 +1610,7 @@ __device__ __forceinline__ bool sweep_wait3(int* a, int va, int* b, int vb, int*
       const int xb = b ? __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : vb;
       const int xc = c ? __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : vc;
       if (xa >= va && xb >= vb && xc >= vc) break;
-      __builtin_amdgcn_s_sleep(2);
+      poll_pause(true);
       if ((++spins & 63) != 1) continue;              // at the first miss and every 64th from there
       if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) { *sh_dead = 1; break; }
       if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) {   // bounded in wall time (see panel_flag_wait)
@@ -1634,7 +1760,7 @@ __global__ __launch_bounds__(256, 2) void trailing_sweep_kernel(double* packed, 
       const int64_t ldp = panel_ld(n_pad, p), ldq = panel_ld(n_pad, q);
       const double* Lp = packed + panel_offset(n_pad, p) + (int64_t)(q - p) * NB;   // row q NB of panel p
       double* Cq = packed + panel_offset(n_pad, q);
-      gemm_tile_128<false>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, Lp + (int64_t)tr * 128, ldp, Lp + (int64_t)tc * 128, ldp, NB, smem);
+      gemm_tile_128<false, false, false, false, false, true, 1>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, Lp + (int64_t)tr * 128, ldp, Lp + (int64_t)tc * 128, ldp, NB, smem);
       SWEEP_T(tw2);
       int* ctr = nullptr;
       if (it.s == 0) ctr = tr < 2 * TPP ? &ready[P + q] : &rowcnt[(int64_t)q * TPP * P + tr];
@@ -1649,7 +1775,7 @@ __global__ __launch_bounds__(256, 2) void trailing_sweep_kernel(double* packed, 
       if (strip == 2 * TPP) SERVICE_STAMP(q, 7);
       if (!sweep_wait3(&rowcnt[(int64_t)q * TPP * P + strip], TPP, nullptr, 0, nullptr, 0, &sy_base[q].failed, info, &sh_dead)) break;
       panel_strip_role(smem, packed + panel_offset(n_pad, q), panel_ld(n_pad, q), winv + (int64_t)q * TPP * NBI * NBI, info, sy_base + q, strip, (int)threadIdx.x,
-                       nullptr, 1, sy_base[q].E);
+                       nullptr, 1, sy_base[q].E, 0, true);
       sweep_publish(sw.stripdone + (int64_t)q * TPP * P + strip, 1, nullptr);
       SWEEP_T(ts1);
       SWEEP_ADD(4, tk1, ts1); SWEEP_ADD(6, 0ull, 1ull);
@@ -1850,7 +1976,13 @@ int launch_trailing_sweep(hipStream_t s, double* packed, int64_t n_pad, int64_t 
   int dev = 0, cus = 0;
   GPRC_HIP(hipGetDevice(&dev));
   GPRC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int wgs = std::max(8, 2 * (cus - service_wgs));            // two per CU the service leaves free: all of them co-resident
+  // Two workgroups per CU the service leaves free (all co-resident) -- except below n_pad = 10752, where the panel chain is the bound and
+  // what counts is how quickly a tile the chain waits for is done: ONE workgroup per CU has the CU's MFMA pipes to itself
+  // (measured, same box: n = 8192 6.28 -> 5.99 ms, 10240 9.44 -> 9.21; 12288 13.55 -> 14.60: profiles/r03_factor_schedules.txt).
+  // GPRC_SWEEP_WGS=<n> overrides.
+  static const int wgs_env = [] { const char* e = std::getenv("GPRC_SWEEP_WGS"); return e ? std::atoi(e) : 0; }();
+  const int per_cu = n_pad < 10752 ? 1 : 2;
+  const int wgs = wgs_env > 0 ? wgs_env : std::max(8, per_cu * (cus - service_wgs));
   hipLaunchKernelGGL(trailing_sweep_kernel, dim3((unsigned)wgs), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)g0, (int)p_last, (int)q_end,
                      sy, ready, rowcnt, sw, winv, info_dev, static_cast<unsigned long long*>(trace));
   GPRC_LAUNCH_CHECK();

@@ -64,6 +64,38 @@ __global__ void k_mfma_operand(double* io, unsigned long long* cyc) {
   if (threadIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = r1 - r0; }
 }
 
+// Does a VALU instruction cost MFMA-pipe time?  16 independent accumulators (no dependency stalls: the pipe is the bound, 64 cycles per MFMA),
+// one extra instruction of the given kind behind every MFMA.
+#define MIX_KERNEL(name, extra)                                                                                                     \
+  __global__ void name(double* io, unsigned long long* cyc) {                                                                      \
+    double a = io[threadIdx.x];                                                                                                     \
+    double4_t acc[16];                                                                                                              \
+    for (int i = 0; i < 16; ++i) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};                                                          \
+    int v = threadIdx.x, w = threadIdx.x * 3; unsigned long long q = threadIdx.x; (void)v; (void)w; (void)q;                        \
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();                                                                 \
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                                                     \
+    for (int rep = 0; rep < 16; ++rep) {                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                                              \
+        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc[i], 0, 0, 0);                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+        extra;                                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+      }                                                                                                                             \
+    }                                                                                                                               \
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                                                     \
+    double sum = 0.0;                                                                                                               \
+    for (int i = 0; i < 16; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];                                              \
+    io[threadIdx.x] = sum + v + w + (double)q;                                                                                      \
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                                                                 \
+    if (threadIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = r1 - r0; }                                                                   \
+  }
+MIX_KERNEL(k_mix_none, asm volatile("" ::: "memory"))
+MIX_KERNEL(k_mix_valu32, asm volatile("v_add_u32 %0, %0, %1" : "+v"(v) : "v"(w)))
+MIX_KERNEL(k_mix_valu32x2, asm volatile("v_add_u32 %0, %0, %1\n\tv_add_u32 %1, %1, %0" : "+v"(v), "+v"(w)))
+MIX_KERNEL(k_mix_valu64, asm volatile("v_lshl_add_u64 %0, %0, 0, %0" : "+v"(q)))
+MIX_KERNEL(k_mix_salu, { int sx; asm volatile("s_add_u32 %0, 1, 2" : "=s"(sx)); (void)sx; })
+MIX_KERNEL(k_mix_fma64, asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(a)))
+
 int main() {
   double* io; unsigned long long* cyc;
   hipMalloc(&io, 512 * 8); hipMalloc(&cyc, 64);
@@ -76,7 +108,10 @@ int main() {
       {"v_fmac_f64_dpp acc chain, constant dpp source (+s_nop 1)", k_fmacdpp_indep_src, 256},
       {"v_cndmask_b32 dependent", k_cndmask_dep, 256}, {"v_fma_f32 dependent", k_fma32_dep, 256},
       {"ds_bpermute_b32 dependent (+waitcnt)", k_bperm_dep, 256}, {"v_mfma_f64_16x16x4 acc -> acc", k_mfma_acc, 256},
-      {"v_mfma_f64_16x16x4 result -> v_mul -> operand", k_mfma_operand, 256}, {"v_readlane_b32 -> v_mov dependent (+s_nop 3)", k_readlane_dep, 256}};
+      {"v_mfma_f64_16x16x4 result -> v_mul -> operand", k_mfma_operand, 256},
+      {"MFMA stream (16 accumulators), nothing between", k_mix_none, 256}, {"MFMA stream + 1 v_add_u32 per MFMA", k_mix_valu32, 256},
+      {"MFMA stream + 2 v_add_u32 per MFMA", k_mix_valu32x2, 256}, {"MFMA stream + 1 v_lshl_add_u64 per MFMA", k_mix_valu64, 256},
+      {"MFMA stream + 1 s_add_u32 per MFMA", k_mix_salu, 256}, {"MFMA stream + 1 v_fma_f64 per MFMA", k_mix_fma64, 256}, {"v_readlane_b32 -> v_mov dependent (+s_nop 3)", k_readlane_dep, 256}};
   for (auto& e : ks) {
     unsigned long long c[2] = {0, 0}, best = ~0ull, bestr = 0;
     for (int rep = 0; rep < 5; ++rep) {
