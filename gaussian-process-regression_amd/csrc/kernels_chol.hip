@@ -388,7 +388,8 @@ __device__ __forceinline__ const char* strip_ktile_s(const double* B, int64_t ld
 // with the larger body (their tiles are short -- K = 128..384 -- and paced by flags, not by the loop).
 // CORE (interleaved loops only): 2 = the loop without VALU instructions (the plain throughput kernels), 1 = the first interleaved loop
 // (kept for the tiles that run beside the factor service -- sweep kernel, trailing_service_kernel: measured, see the loops' comments).
-template <bool SET, bool SEG = false, bool SEGA = false, bool SSQ = false, bool LDSOUT = false, bool ILV = true, int CORE = 2>
+// WT: the tile is stored WRITE-THROUGH (sc1: global_store ... sc1, the agent-scope relaxed atomic store), leaving no dirty line in the XCD's L2.
+template <bool SET, bool SEG = false, bool SEGA = false, bool SSQ = false, bool LDSOUT = false, bool ILV = true, int CORE = 2, bool WT = false>
 __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                                               int64_t ldb, int K, double* smem, int64_t brow = 0, int64_t arow = 0, int kt0 = 0,
                                               double* ssq = nullptr, int tid = -1, double* lds_out = nullptr) {
@@ -699,7 +700,10 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) Cw[m * 16 + (int64_t)(n * 16 + 4 * r) * ldc] = acc[m][n][r];
+      for (int m = 0; m < 4; ++m) {
+        if constexpr (WT) __hip_atomic_store(&Cw[m * 16 + (int64_t)(n * 16 + 4 * r) * ldc], acc[m][n][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else Cw[m * 16 + (int64_t)(n * 16 + 4 * r) * ldc] = acc[m][n][r];
+      }
 
   if constexpr (LDSOUT) {
     __syncthreads();  // every wave is past its last operand read: the staging buffers are free
@@ -1628,11 +1632,13 @@ __device__ __forceinline__ bool sweep_wait3(int* a, int va, int* b, int vb, int*
 }
 
 // the item is complete: its flag (a version or a strip's "done"), and (may be null) one count for the service / the strips
-__device__ __forceinline__ void sweep_publish(int* flag, int value, int* ctr) {
+// written_through: every byte of the item was stored sc1 (gemm_tile_128<.., WT>): nothing of it is dirty in L2, no write-back needed
+// (the microarchitecture guide's form "sc1 payload -> every wave's vmcnt(0) -> barrier -> sc1 flag"; the consumers acquire as always)
+__device__ __forceinline__ void sweep_publish(int* flag, int value, int* ctr, bool written_through = false) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (!written_through) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ctr) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1760,12 +1766,15 @@ __global__ __launch_bounds__(256, 2) void trailing_sweep_kernel(double* packed, 
       const int64_t ldp = panel_ld(n_pad, p), ldq = panel_ld(n_pad, q);
       const double* Lp = packed + panel_offset(n_pad, p) + (int64_t)(q - p) * NB;   // row q NB of panel p
       double* Cq = packed + panel_offset(n_pad, q);
-      gemm_tile_128<false, false, false, false, false, true, 1>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, Lp + (int64_t)tr * 128, ldp, Lp + (int64_t)tc * 128, ldp, NB, smem);
+      // (CORE = 1: see the loops' comments.  WT: the tile is stored write-through, so that its publication needs no write-back of the XCD's
+      //  L2 -- a release fence per tile, by ~60 workgroups per XCD, each flushing what all of them have dirtied since the last one, was
+      //  2 % of the mid-size factorisation: n = 16384 27.42 -> 26.84 ms, 8192 5.98 -> 5.81, same box)
+      gemm_tile_128<false, false, false, false, false, true, 1, true>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, Lp + (int64_t)tr * 128, ldp, Lp + (int64_t)tc * 128, ldp, NB, smem);
       SWEEP_T(tw2);
       int* ctr = nullptr;
       if (it.s == 0) ctr = tr < 2 * TPP ? &ready[P + q] : &rowcnt[(int64_t)q * TPP * P + tr];
       else if (it.flags & SWEEP_SIG_D2) ctr = &ready[2 * P + q];
-      sweep_publish(verp, stage + 1, ctr);
+      sweep_publish(verp, stage + 1, ctr, true);
       SWEEP_T(tw3);
       SWEEP_ADD(1, tw0, tw1); SWEEP_ADD(2, tw1, tw2); SWEEP_ADD(3, tw2, tw3); SWEEP_ADD(5, 0ull, 1ull);
       if (it.flags & SWEEP_FIRST) SERVICE_STAMP(p, 11);
