@@ -172,7 +172,9 @@ def test_golden_gpc(golden):
 # ---- against the oracle on seeded inputs --------------------------------------------------------------
 KERNELS = [("constant", dict(c=1.7)), ("linear", dict(sigma=0.7)), ("polynomial", dict(sigma=0.5, p=3.0)),
            ("polynomial", dict(sigma=0.25, p=2.0)), ("sqrexp", dict(l=1.3)), ("gammaexp", dict(l=0.9, gamma=1.5)),
-           ("gammaexp", dict(l=0.9, gamma=2.0)), ("rationalquadratic", dict(l=1.1, alpha=1.5))]
+           ("gammaexp", dict(l=0.9, gamma=2.0)), ("rationalquadratic", dict(l=1.1, alpha=1.5)),
+           ("rationalquadratic", dict(l=0.8, alpha=0.7)),    # general alpha: exp(-alpha log q)
+           ("rationalquadratic", dict(l=0.9, alpha=3.5)), ("rationalquadratic", dict(l=1.2, alpha=0.5))]   # half-integer alpha: the rsqrt form
 
 
 @pytest.mark.parametrize("d,nA,nB", [(1, 1, 1), (1, 5, 3), (2, 130, 67), (8, 257, 300), (20, 64, 129), (37, 300, 10)])
