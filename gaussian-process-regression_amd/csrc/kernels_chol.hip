@@ -526,7 +526,7 @@ __device__ __forceinline__ void gemm_tile_128(double* C, int64_t ldc, const doub
     if (more1) { GPRC_READY(8, a3, b3) } else { GPRC_READY(0, a3, b3) }                                             \
     GPRC_BLOCK_R(a3, b3, 1 - (buf), 1, a1, b1, more1)                                                               \
   }
-  {   // KT is even and >= 4: every caller's K is a multiple of 128 (eight k-tiles)
+  {   // KT is even and >= 4: every caller's K is a multiple of 128 (eight k-tiles); launch_gemm_nt, the one launcher with a free K, checks it
     int kt = 0;
     for (; kt + 2 < KT; kt += 2) {
       GPRC_KTILE(0, true, true)
@@ -2097,7 +2097,8 @@ int launch_trsm_panel(hipStream_t s, double* X, int64_t ldx, int64_t M, const do
 int launch_gemm_nt(hipStream_t s, double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
                    int64_t M, int64_t N, int64_t K, int lower, int kind) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  if (M % 128 || N % 128 || K % G_KB || (lda & 1) || (ldb & 1)) { set_error("gemm_nt: bad shape"); return GPRC_ERR_ARG; }
+  // (K: the tile loop runs two k-tiles of 16 per iteration and needs at least four: every caller's K is a multiple of 128)
+  if (M % 128 || N % 128 || K % (2 * G_KB) || K < 4 * G_KB || (lda & 1) || (ldb & 1)) { set_error("gemm_nt: bad shape"); return GPRC_ERR_ARG; }
   GPRC_TRY(ensure_gemm_attrs());
   const int64_t tiles = (M / 128) * (N / 128);
   if (tiles > 0x7fffffff) { set_error("gemm_nt: too many tiles"); return GPRC_ERR_ARG; }

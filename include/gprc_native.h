@@ -202,8 +202,9 @@ GPRC_API int gprc_dev_factor_panel(gprc_ctx* ctx, double* packed, int64_t n_pad,
 GPRC_API int gprc_dev_factor_subpanel(gprc_ctx* ctx, double* packed, int64_t n_pad, int64_t p, int j, int part, double* winv,
                              int* info_dev);
 /* All panels of an already filled packed matrix on ONE GPU, asynchronously on the context's stream (the one-rank form of
- * the factor_panel / update_trailing sweep: the panels in groups, a left-looking pass per group, the factor service inside
- * the group; one group below n_pad = 20480): results bit-identical to that sweep.
+ * the factor_panel / update_trailing sweep: the panels in groups, a left-looking pass per group, inside the group two persistent
+ * launches side by side -- the factor service (the panels' dependent chains) and the sweep kernel (every other tile and strip of the
+ * group, dealt by tickets; GPRC_SWEEP=0: one launch per panel instead); one group below n_pad = 20480): results bit-identical to that sweep.
  * info_dev: one device int, zeroed by the caller, receives LAPACK's info (first non-PD leading minor) if any.
  * inv: NULL, or gprc_solve_inv_size(n_pad) doubles that receive what gprc_dev_solve_prepare would compute for all panels. */
 GPRC_API int gprc_dev_factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev, double* inv);
