@@ -396,3 +396,36 @@ def test_two_contexts_factor_many_times_and_every_word_agrees():
     [t.start() for t in ts]
     [t.join(timeout=300) for t in ts]
     assert not errs and sorted(done) == [0, 1], errs
+
+
+def test_one_launch_per_panel_under_the_service_is_still_bit_identical(tmp_path):
+    """GPRC_SWEEP=0 keeps round 2's form of the caller's-stream work (one trailing_service_kernel per panel instead of the persistent
+    sweep kernel).  The switch is read once per process, so a child process factors with it and compares every word with the
+    factor_panel / update_trailing sweep, as test_factor_service_is_bit_identical_to_the_launch_per_panel_sweep does for the default."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "import tests.test_gpu_device_level as t\n"
+        "from gprc_amd import _native as nat\n"
+        "for n in (1536, 9100):\n"
+        "    L, ctx, g, K = t._filled(n, seed=5)\n"
+        "    a = t._clone(K); w, info = t._new(g)\n"
+        "    for p in range(g.P):\n"
+        "        nat.check(L.gprc_dev_factor_panel(ctx.handle, a.data_ptr(), g.n_pad, p, w.data_ptr(), info.data_ptr()))\n"
+        "        if p + 1 < g.P:\n"
+        "            nat.check(L.gprc_dev_update_trailing(ctx.handle, a.data_ptr(), g.n_pad, p, p + 1, g.P, 1))\n"
+        "    torch.cuda.synchronize()\n"
+        "    b = t._clone(K); w2, info2 = t._new(g)\n"
+        "    nat.check(L.gprc_dev_factor_all(ctx.handle, b.data_ptr(), g.n_pad, w2.data_ptr(), info2.data_ptr(), None))\n"
+        "    torch.cuda.synchronize()\n"
+        "    assert int(info[0]) == 0 and int(info2[0]) == 0\n"
+        "    assert torch.equal(b, a) and torch.equal(w2, w), n\n"
+        "    ctx.close()\n"
+        "print('SWEEP0_OK')\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPRC_SWEEP="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SWEEP0_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
