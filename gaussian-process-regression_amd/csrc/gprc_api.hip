@@ -476,8 +476,8 @@ int factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* 
   GPRC_HIP(hipMemcpyAsync(info_host, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
   GPRC_HIP(hipStreamSynchronize(s));
   if (*info_host < 0) {
-    set_error("factorisation: a device-side dependency wait timed out (info = " + std::to_string(*info_host) +
-              "); the factor is not valid.  The factor service needs its persistent launch and the caller's kernels to run CONCURRENTLY: "
+    set_error("factorisation: a device-side dependency wait timed out (info = " + std::to_string(*info_host) + ")" + wait_timeout_report() +
+              "; the factor is not valid.  The factor service needs its persistent launch and the caller's kernels to run CONCURRENTLY: "
               "under a tool that serialises dispatches (e.g. rocprofv3 --pmc) set GPRC_SERVICE=0");
     return GPRC_ERR_HIP;
   }

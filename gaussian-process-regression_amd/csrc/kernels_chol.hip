@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(256, 2) void trailing_range_kernel(double* packed, 
 // barrier, one lane's agent release fence + vmcnt(0), relaxed agent store of the flag; one lane polls with relaxed agent
 // loads, agent acquire fence + vmcnt(0), workgroup barrier, plain / LDS-DMA loads).
 // ------------------------------------------------------------------------------------------------
-struct PanelSync { int ticket; int failed; int W[4]; int E[4]; int R[4]; int LA; int pad; };   // 16 ints, zeroed before the launch
+struct PanelSync { int ticket; int failed; int W[4]; int E[4]; int R[4]; int LA; int SU; };   // 16 ints, zeroed before the launch
 static_assert(TPP <= 4, "PanelSync holds four flags of each kind and LA four 8-bit fields: the factor service is written for NB = 4 x 128");
 // Bound of every device-side dependency wait: WALL time (s_memrealtime, 100 MHz), not a poll count -- a busy, shared GPU slows the
 // polls down but must not shorten the patience.  Legitimate waits are below 10 ms (one trailing update at n <= 24576).
@@ -1077,7 +1077,20 @@ constexpr unsigned long long WAIT_LIMIT_TICKS = 400000000ULL;   // 4 s
 //  the round-2 form -- reads "4 (j + 1)" also when one strip is a sub-step ahead and another one behind, which happens as soon as
 //  the service's workgroups do not start together (another context's kernels on the GPU): profiles/r03_la_counter_race.txt.
 //  A strip goes through its blocks in order, so field TPP - 1 = TPP -- LA >= TPP << 24 -- means rows [NB, 2 NB) are final;
-//  E[0], E[1]: blocks (s, j <= s-2) the diagonal strips s = 2, 3 have finished)
+//  E[0], E[1]: blocks (s, j <= s-2) the diagonal strips s = 2, 3 have finished;
+//  SU: the split chain's counters, eight 4-bit fields -- field j: 32-row slices of L(j, j-1) that are final (the chain helpers' solve
+//  phase), field 4 + j: slices of block (j, j) that have received L(j, j-1) (their update phase); each reaches CHAIN_HELPERS)
+
+// Who gave up, and on what: the FIRST wait of a factorisation that runs out its bound leaves a record for the host's error message
+// (wait_timeout_report) -- [0] site (1 flag, 2 count, 3 field, 4 chain, 5 sweep, 6 gate), [1] blockIdx.x, [2] gridDim.x,
+// [3] the value needed, [4] the value seen, [5] the awaited word's index inside its panel's PanelSync (or its distance from it),
+// [6] threads per workgroup
+__device__ int g_wait_diag[8];
+__device__ __attribute__((noinline)) void wait_diag(int site, int need, int seen, const int* word, const void* sy) {
+  if (atomicCAS(&g_wait_diag[0], 0, site) != 0) return;
+  g_wait_diag[1] = (int)blockIdx.x; g_wait_diag[2] = (int)gridDim.x; g_wait_diag[3] = need; g_wait_diag[4] = seen;
+  g_wait_diag[5] = sy ? (int)(word - static_cast<const int*>(sy)) : -1; g_wait_diag[6] = (int)blockDim.x;
+}
 
 // relaxed: the caller is throughput work (a strip riding in the sweep kernel), not a role of the chain: it looks at the flag once per
 // microsecond instead of every ~50 ns.  Hundreds of workgroups polling flags and counters at full rate slow every device-scope access
@@ -1103,6 +1116,7 @@ __device__ __forceinline__ void panel_flag_wait(int* flag, PanelSync* sy, int* i
       // for ever): after WAIT_LIMIT_TICKS of wall time give up, let the grid drain, and tell the host through the ONE word it
       // always reads after a factorisation -- info = GPRC_INFO_WAIT_TIMEOUT (< 0; LAPACK infos are > 0)
       if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) {
+        wait_diag(1, 1, 0, flag, sy);
         __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
         break;
@@ -1134,6 +1148,7 @@ __device__ __forceinline__ void panel_ready_wait(int* ctr, int need, PanelSync* 
       if ((++spins & 255) != 0) continue;
       if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
       if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) {   // bounded in wall time (see panel_flag_wait)
+        wait_diag(2, need, __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ctr, sy);
         __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
         break;
@@ -1156,6 +1171,7 @@ __device__ __forceinline__ void panel_field_wait(int* ctr, int shift, int need, 
       if ((++spins & 255) != 0) continue;
       if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
       if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) {   // bounded in wall time (see panel_flag_wait)
+        wait_diag(3, need << shift, __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ctr, sy);
         __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
         break;
@@ -1182,6 +1198,180 @@ __device__ __forceinline__ void panel_count_publish(int* ctr, int add) {      //
 __device__ __forceinline__ void gemm_tile_shadow_barriers(int K) {
   const int KT = K / G_KB;
   for (int b = 0; b < KT; ++b) __builtin_amdgcn_s_barrier();
+}
+
+// ------------------------------------------------------------------------------------------------
+// The SPLIT chain (factor service only).  Between two diagonal blocks of a panel the chain runs two 128 x 128 x 128 tiles -- the solve
+// L(j+1, j) = C'(j+1, j) Winv_j^T and the update C(j+1, j+1) -= L(j+1, j) L(j+1, j)^T -- and on ONE CU each is bound by that CU's MFMA
+// rate (13.7 us of MFMAs + 3.5 us of prologue: 17.4 and 20.5-24 us measured, profiles/r03_chain_traces_after_diag16.txt; a second team
+// on the same CU changes nothing).  Here CHAIN_HELPERS = 4 resident workgroups (8 waves each, a CU each) take 32 ROWS of both tiles
+// each: a quarter of the MFMAs (3.4 us), operands loaded in one go (the slice's 32 x 128 A rows through LDS, every wave's 16 B rows
+// straight into registers), results stored write-through (sc1) and handed on by counters -- solve slices to each other (the update
+// needs all of L(j+1, j)), update slices to the factor role, which then loads the block itself (potf2_blocked_body, not preloaded).
+// Every output element is still acc = C (or 0), then for the k-steps 0..31 ascending acc = v_mfma_f64_16x16x4(B strip value, A strip
+// value, acc) with the update's negate-A bit: the same operand roles, k order and accumulator start as gemm_tile_128 -- identical bits.
+// ------------------------------------------------------------------------------------------------
+#ifdef GPRC_CHAIN_PROF
+constexpr int GPRC_CHAIN_PROF_PANEL = GPRC_CHAIN_PROF;
+#else
+constexpr int GPRC_CHAIN_PROF_PANEL = -1;
+#endif
+constexpr int CHAIN_HELPERS = 4;                  // 32-row slices of a 128-row block
+constexpr int CHAIN_LDS_LD = 48;                  // doubles per k-slice of the A image: 32 rows + 16 pad (consecutive k-slices 32 banks apart)
+static_assert(CHAIN_HELPERS * 32 == 128 && CHAIN_HELPERS < 16, "SU holds 4-bit counts of 32-row slices");
+
+#ifdef GPRC_CHAIN_PROF
+// measurement build: s_memrealtime stamps (100 MHz) of panel GPRC_CHAIN_PROF's chain -- [0..31] helper 0 (8 per sub-step: W seen,
+// operands in, MFMAs done, stored + counted, S seen, operands in, MFMAs done, stored + counted), [32 + 4 j ..] the factor role
+// (U seen, potf2 done, W published)
+__device__ unsigned long long g_chain_prof[64];
+#define CHAIN_STAMP(on, k) do { if ((on) && threadIdx.x == 0) g_chain_prof[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CHAIN_STAMP(on, k)
+#endif
+
+// waits until ((*a >> sa) & ma) >= va and (b == null or *b >= vb); the whole workgroup calls it; the polls fly together
+__device__ __forceinline__ void chain_wait2(int* a, int sa, int ma, int va, int* b, int vb, PanelSync* sy, int* info) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+      const int xa = (__hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> sa) & ma;
+      const int xb = b ? __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : vb;
+      if (xa >= va && xb >= vb) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 255) != 0) continue;
+      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) {   // bounded in wall time (see panel_flag_wait)
+        if (xa < va) wait_diag(4, va << sa, __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a, sy);
+        else wait_diag(4, vb, xb, b, sy);
+        __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
+// C (32 rows x 128 columns, column-major) = (SET ? 0 : C) -/+ A (32 x 128) B (128 x 128)^T on 512 threads: wave w the columns
+// [16 w, 16 w + 16).  lds: 128 x CHAIN_LDS_LD doubles.  C may be A (the solve in place: every A element is in LDS before the first
+// store).  Stores are write-through; the caller publishes (every wave's vmcnt(0), barrier, counter).
+template <bool SET>
+__device__ __forceinline__ void chain_slice_32(double* C_, int64_t ldc, const double* A_, int64_t lda, const double* B_, int64_t ldb, double* lds_,
+                                               bool prof = false, int stamp0 = 0) {
+  // explicit address spaces: inside a non-inlined role the pointers are generic, and FLAT loads would tie the LDS waits to the
+  // outstanding global loads (a flat instruction counts in vmcnt and lgkmcnt)
+  typedef __attribute__((address_space(1))) double gdouble;
+  typedef __attribute__((address_space(3))) double ldouble;
+  gdouble* C = (gdouble*)C_;
+  const gdouble* A = (const gdouble*)A_;
+  const gdouble* B = (const gdouble*)B_;
+  ldouble* lds = (ldouble*)lds_;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int fk = lane >> 4, fr = lane & 15;
+  constexpr int NEG = SET ? 0 : 1;
+  // the A slice: thread t brings rows [8 (t & 3), +8) of k-slice t >> 2
+  const gdouble* asrc = A + 8 * (t & 3) + (int64_t)(t >> 2) * lda;
+  double av[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) av[i] = asrc[i];
+  double4_t acc[2];
+  gdouble* Cw = C + fr + (int64_t)(16 * wave + fk) * ldc;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = SET ? 0.0 : Cw[16 * m + (int64_t)(4 * r) * ldc];
+  // this wave's 16 B rows, all 32 k-steps: one double per lane and step
+  const gdouble* bsrc = B + (16 * wave + fr) + (int64_t)fk * ldb;
+  double b[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) b[s] = bsrc[(int64_t)(4 * s) * ldb];
+  ldouble* adst = lds + (t >> 2) * CHAIN_LDS_LD + 8 * (t & 3);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) adst[i] = av[i];
+  __syncthreads();
+  const ldouble* ap = lds + fk * CHAIN_LDS_LD + fr;
+  double a0[2], a1[2];   // operand reads two k-steps ahead
+  a0[0] = ap[0]; a1[0] = ap[16];
+  a0[1] = ap[4 * CHAIN_LDS_LD]; a1[1] = ap[4 * CHAIN_LDS_LD + 16];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    const double x0 = a0[s & 1], x1 = a1[s & 1];
+    if (s + 2 < 32) { a0[s & 1] = ap[4 * (s + 2) * CHAIN_LDS_LD]; a1[s & 1] = ap[4 * (s + 2) * CHAIN_LDS_LD + 16]; }
+    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[s], x0, acc[0], 0, 0, NEG);
+    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[s], x1, acc[1], 0, 0, NEG);
+#ifdef GPRC_CHAIN_PROF
+    if (s == 0) CHAIN_STAMP(prof, stamp0);       // the first MFMAs are issued: A image and b[0] are in
+#endif
+  }
+#ifdef GPRC_CHAIN_PROF
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  if (prof && threadIdx.x == 0) { double sink = acc[0][0] + acc[1][3]; asm volatile("" :: "v"(sink)); g_chain_prof[stamp0 + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) __hip_atomic_store(&Cw[16 * m + (int64_t)(4 * r) * ldc], acc[m][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the slice is stored: every wave's vmcnt(0), barrier, then one lane adds `add` to *ctr (write-through payload: no write-back).
+// Returns (to thread 0 only) the counter's previous value.
+__device__ __forceinline__ int chain_publish(int* ctr, int add) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  return threadIdx.x == 0 ? __hip_atomic_fetch_add(ctr, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+}
+
+// Chain helper q of one panel (512 threads): rows [32 q, 32 q + 32) of the solve tile of every sub-step and of EVERY update of the
+// diagonal blocks (1,1), (2,2), (3,3) -- the one the next potf2 waits for, and, in the 35 us that potf2 then runs, the updates of the
+// later diagonal blocks with the column just finished (the diagonal strips' own share in the unsplit form: with the two chain tiles
+// down from 38 to 17 us the chain waited 29 us for strip 3's K = 256 tiles, tools/chain_prof.py).  A helper touches only its own 32
+// rows of those blocks, k-chunk after k-chunk in order: no flag between them, and the same accumulator chain through memory.
+// strip_progress: E[0] / E[1], the finished blocks (s, j <= s-2) of the diagonal strips s = 2, 3.
+__device__ __attribute__((noinline)) void panel_chain_helper_role(double* sm, double* pan, int64_t ld, double* wp, int* info, PanelSync* sy, int q,
+                                                                  bool prof) {
+  for (int j = 0; j + 1 < TPP; ++j) {
+    double* Cn = pan + (int64_t)(j + 1) * NBI + (int64_t)j * NBI * ld;            // block (j+1, j)
+    double* Dn = pan + (int64_t)(j + 1) * NBI + (int64_t)(j + 1) * NBI * ld;      // block (j+1, j+1)
+    const int fs = 4 * (j + 1), fu = 16 + 4 * (j + 1);
+    // solve: W_j published; j > 0: block (j+1, j) has received the columns left of block j (E = 1, the diagonal strip j+1)
+    chain_wait2(&sy->W[j], 0, 1, 1, j > 0 ? &sy->E[j + 1] : nullptr, 1, sy, info);
+    CHAIN_STAMP(prof, 8 * j);
+    chain_slice_32<true>(Cn + 32 * q, ld, Cn + 32 * q, ld, wp + (int64_t)j * NBI * NBI, 128, sm, prof, 8 * j + 1);
+    const int before = chain_publish(&sy->SU, 1 << fs);
+    CHAIN_STAMP(prof, 8 * j + 3);
+    // the last slice completes L(j+1, j): R_{j+1} for the strips (every slice was written through and had landed before its count)
+    if (threadIdx.x == 0 && ((before >> fs) & 15) == CHAIN_HELPERS - 1) __hip_atomic_store(&sy->R[j + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // update: all four slices of L(j+1, j)
+    chain_wait2(&sy->SU, fs, 15, CHAIN_HELPERS, nullptr, 0, sy, info);
+    CHAIN_STAMP(prof, 8 * j + 4);
+    chain_slice_32<false>(Dn + 32 * q, ld, Cn + 32 * q, ld, Cn, ld, sm, prof, 8 * j + 5);
+    (void)chain_publish(&sy->SU, 1 << fu);
+    CHAIN_STAMP(prof, 8 * j + 7);
+    // while the factor role is busy with block (j+1, j+1): column j into the later diagonal blocks
+    for (int s = j + 2; s < TPP; ++s) {
+      double* Ls = pan + (int64_t)s * NBI + (int64_t)j * NBI * ld;                // L(s, j), solved by diagonal strip s
+      chain_wait2(&sy->E[s - 2], 0, 0xffff, j + 1, nullptr, 0, sy, info);
+      chain_slice_32<false>(pan + (int64_t)s * NBI + (int64_t)s * NBI * ld + 32 * q, ld, Ls + 32 * q, ld, Ls, ld, sm);
+    }
+  }
+}
+
+// The factor role beside the chain helpers: the four diagonal blocks, each loaded when its update slices are complete.
+__device__ __forceinline__ void panel_factor_role_split(double* sm, double* pan, int64_t ld, double* wp, int* info, int p, PanelSync* sy) {
+  for (int j = 0; j < TPP; ++j) {
+    if (j > 0) chain_wait2(&sy->SU, 16 + 4 * j, 15, CHAIN_HELPERS, nullptr, 0, sy, info);
+    CHAIN_STAMP(p == GPRC_CHAIN_PROF_PANEL, 32 + 4 * j);
+    potf2_blocked_body<8>(sm, pan + (int64_t)j * NBI + (int64_t)j * NBI * ld, ld, wp + (int64_t)j * NBI * NBI, info, p * NB + j * NBI, nullptr, false);
+    CHAIN_STAMP(p == GPRC_CHAIN_PROF_PANEL, 33 + 4 * j);
+    panel_flag_publish(&sy->W[j]);
+    CHAIN_STAMP(p == GPRC_CHAIN_PROF_PANEL, 34 + 4 * j);
+  }
 }
 
 // trace (may be null): the factor role's lane 0 leaves s_memrealtime stamps (100 MHz) of its stages there -- measurement only
@@ -1229,7 +1419,8 @@ __device__ __forceinline__ void panel_factor_role(double* sm, double* pan, int64
 // and only the last chunk (columns of block j-1) after R_j: the same products in the same order, continued through memory.
 // progress_shift: the count of block (s, j) goes to the 8-bit field j of *progress (teams << progress_shift j; 0: one plain sum).
 __device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int64_t ld, double* wp, int* info, PanelSync* sy, int s, int tid,
-                                                 int* progress = nullptr, int teams = 1, int* early = nullptr, int progress_shift = 0, bool relaxed = false) {
+                                                 int* progress = nullptr, int teams = 1, int* early = nullptr, int progress_shift = 0, bool relaxed = false,
+                                                 bool skip_diag = false) {
   if (s < 2) return;
   const double* Arow = pan + (int64_t)s * 128;     // my 128 rows of the panel
   const int jlast = s < TPP ? s - 2 : TPP - 1;     // a diagonal strip solves blocks (s, 0..s-2) itself
@@ -1263,6 +1454,7 @@ __device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int6
     panel_flag_wait(&sy->R[s - 1], sy, info, relaxed);
     gemm_tile_128<false, false, false, false, false, false>(pan + (int64_t)s * 128 + K * ld, ld, Arow, ld, pan + K, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
     panel_count_publish(&sy->E[s], 1);
+    if (skip_diag) return;                         // split chain: the chain helpers apply every update of the diagonal blocks themselves
     gemm_tile_128<false, false, false, false, false, false>(pan + (int64_t)s * 128 + (int64_t)s * NBI * ld, ld, Arow, ld, Arow, ld, (int)K, smem, 0, 0, 0, nullptr, tid);
     panel_count_publish(&sy->E[s], 1);
   }
@@ -1375,7 +1567,8 @@ constexpr int PANEL_LA_TILES = TPP * TPP;             // tiles of a panel's rows
 constexpr int SERVICE_LA0 = 3;                                   // first look-ahead strip role (one 4-wave team per workgroup)
 constexpr int SERVICE_D0 = SERVICE_LA0 + TPP;                    // first next-diagonal-block role (one tile per workgroup)
 constexpr int SERVICE_INV0 = SERVICE_D0 + PANEL_DIAG_TILES;     // first explicit-inverse role (one block row of inv(L_pp)^T each)
-constexpr int SERVICE_WGS = SERVICE_INV0 + TPP;
+constexpr int SERVICE_H0 = SERVICE_INV0 + TPP;                   // first chain helper (split chain only; 8 waves each)
+constexpr int SERVICE_WGS = SERVICE_H0 + CHAIN_HELPERS;
 
 // One team's share of the next diagonal block: lower tile `idx` (0..9: (0,0) (1,0) (1,1) (2,0) ...) of the block, in four k-chunks.
 __device__ __forceinline__ void panel_next_diag_role(double* smem, const double* pan, int64_t ld, double* Dn, int64_t ldn, int* info,
@@ -1403,13 +1596,15 @@ __device__ __forceinline__ void panel_next_diag_role(double* smem, const double*
 // complete when the launch starts; the next diagonal block is updated only inside the group (the panel behind the group receives
 // everything in its left-looking pass, k ascending), the look-ahead strips are solved for every panel that has rows below it.
 __global__ __launch_bounds__(512) void panel_service_kernel(double* packed, int64_t n_pad, double* winv, int* info, PanelSync* sy_base,
-                                                            int* ready, int P, unsigned long long* trace, double* inv, int p_begin, int p_end) {
+                                                            int* ready, int P, unsigned long long* trace, double* inv, int p_begin, int p_end,
+                                                            int split) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int role = blockIdx.x;
   const int t = threadIdx.x, team = t >> 8, tid = t & 255;
   if (t == 0) __hip_atomic_fetch_add(&ready[3 * P], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident: see service_gate_kernel
-  if (role >= 1 && team == 1) return;                // every role but the factor role is one 4-wave team
-  if (role >= SERVICE_INV0 && !inv) return;
+  if (role >= SERVICE_H0) { if (!split) return; }    // the chain helpers: all 8 waves
+  else if (role >= 1 && team == 1) return;           // every other role but the factor role is one 4-wave team
+  if (role >= SERVICE_INV0 && role < SERVICE_H0 && !inv) return;
   for (int p = p_begin; p < p_end; ++p) {
     PanelSync* sy = sy_base + p;
     const int64_t ld = panel_ld(n_pad, p);
@@ -1419,9 +1614,13 @@ __global__ __launch_bounds__(512) void panel_service_kernel(double* packed, int6
       if (role == 0) SERVICE_STAMP(p, 14);
       if (p > p_begin) panel_ready_wait(&ready[p], PANEL_DIAG_TILES, sy, info);
       if (role == 0) SERVICE_STAMP(p, 0);
-      if (role == 0) panel_factor_role(sm, pan, ld, wp, info, p, sy, nullptr);
-      else panel_strip_role(sm, pan, ld, wp, info, sy, role + 1, tid, &sy->E[role - 1], 1);
+      if (role == 0) {
+        if (split) panel_factor_role_split(sm, pan, ld, wp, info, p, sy);
+        else panel_factor_role(sm, pan, ld, wp, info, p, sy, nullptr);
+      } else panel_strip_role(sm, pan, ld, wp, info, sy, role + 1, tid, &sy->E[role - 1], 1, nullptr, 0, false, split != 0);
       if (role == 0) SERVICE_STAMP(p, 1);
+    } else if (role >= SERVICE_H0) {
+      panel_chain_helper_role(sm, pan, ld, wp, info, sy, role - SERVICE_H0, role == SERVICE_H0 && p == GPRC_CHAIN_PROF_PANEL);   // paced by this panel's W flags
     } else if (role >= SERVICE_INV0) {
       inv512_row_role(sm, pan, ld, wp, inv + (int64_t)p * NB * NB, role - SERVICE_INV0, tid, sy, info);
     } else if (role < SERVICE_D0 ? p + 1 < P : p + 1 < p_end) {
@@ -1452,7 +1651,11 @@ __global__ void service_gate_kernel(int* alive, int need, int* info, unsigned lo
   if (threadIdx.x == 0) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(alive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 >= limit_ticks) { atomicExch(info, GPRC_INFO_WAIT_TIMEOUT); break; }
+      if (__builtin_amdgcn_s_memrealtime() - t0 >= limit_ticks) {
+        wait_diag(6, need, __hip_atomic_load(alive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), alive, nullptr);
+        atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
+        break;
+      }
       __builtin_amdgcn_s_sleep(8);
     }
   }
@@ -1618,6 +1821,7 @@ __device__ __forceinline__ bool sweep_wait3(int* a, int va, int* b, int vb, int*
       if ((++spins & 63) != 1) continue;              // at the first miss and every 64th from there
       if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) { *sh_dead = 1; break; }
       if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) {   // bounded in wall time (see panel_flag_wait)
+        if (xa < va) wait_diag(5, va, xa, a, failed - 1); else if (xb < vb) wait_diag(5, vb, xb, b, failed - 1); else wait_diag(5, vc, xc, c, failed - 1);
         __hip_atomic_store(failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
         *sh_dead = 1;
@@ -1794,6 +1998,25 @@ __global__ __launch_bounds__(256, 2) void trailing_sweep_kernel(double* packed, 
   SWEEP_T(tkern1);
   SWEEP_ADD(7, tkern0, tkern1);
 }
+}  // namespace
+}  // namespace gprc
+// tools only (not part of include/gprc_native.h): the raw record of the first timed-out wait, see wait_diag; clears it
+extern "C" __attribute__((visibility("default"))) int gprc_debug_wait_timeout(int* out8) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gprc::g_wait_diag), 32) != hipSuccess) return -1;
+  const int z[8] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(gprc::g_wait_diag), z, 32) == hipSuccess ? 0 : -1;
+}
+namespace gprc {
+namespace {
+#ifdef GPRC_CHAIN_PROF
+}  // namespace
+}  // namespace gprc
+extern "C" __attribute__((visibility("default"))) int gprc_debug_chain_prof(unsigned long long* out64) {
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(gprc::g_chain_prof), 512) == hipSuccess ? 0 : -1;
+}
+namespace gprc {
+namespace {
+#endif
 #ifdef GPRC_SWEEP_PROF
 }  // namespace
 }  // namespace gprc
@@ -1871,7 +2094,26 @@ int launch_inv512(hipStream_t s, const double* packed, int64_t n_pad, const doub
   return 0;
 }
 
-int service_workgroups(bool with_inverse) { return with_inverse ? SERVICE_WGS : SERVICE_INV0; }
+// GPRC_CHAIN_SPLIT=0 / 1: the factor role's two tiles per sub-step on its own CU / split over the four chain helpers
+bool chain_split() {
+  static const int v = [] { const char* e = std::getenv("GPRC_CHAIN_SPLIT"); return e ? std::atoi(e) : 0; }();
+  return v != 0;
+}
+
+// the record the first timed-out wait left (wait_diag), as text for the host's error message; clears it
+std::string wait_timeout_report() {
+  int v[8] = {};
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_wait_diag), sizeof(v)) != hipSuccess || v[0] == 0) return "";
+  const int z[8] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wait_diag), z, sizeof(z));
+  static const char* const site[] = {"?", "flag", "count", "field", "chain", "sweep", "gate"};
+  return std::string(" [first wait to give up: ") + site[v[0] >= 0 && v[0] <= 6 ? v[0] : 0] + " wait of workgroup " + std::to_string(v[1]) + " of " +
+         std::to_string(v[2]) + " x " + std::to_string(v[6]) + " threads, needed " + std::to_string(v[3]) + ", saw " + std::to_string(v[4]) +
+         ", word " + std::to_string(v[5]) + " of its panel's flags]";
+}
+
+// workgroups the service keeps resident (a CU each)
+int service_workgroups(bool with_inverse) { return SERVICE_INV0 + (with_inverse ? TPP : 0) + (chain_split() ? CHAIN_HELPERS : 0); }
 
 int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync, void* trace, double* inv,
                          int64_t p_begin, int64_t p_end) {
@@ -1888,7 +2130,7 @@ int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* w
   int* ready = reinterpret_cast<int*>(static_cast<char*>(sync) + (size_t)P * sizeof(PanelSync));
   ProfScope ps(s, PK_PANEL_FUSED, 0.0, 0.0);
   hipLaunchKernelGGL(panel_service_kernel, dim3(SERVICE_WGS), dim3(512), smem, s, packed, n_pad, winv, info_dev, sy, ready, (int)P,
-                     static_cast<unsigned long long*>(trace), inv, (int)p_begin, (int)p_end);
+                     static_cast<unsigned long long*>(trace), inv, (int)p_begin, (int)p_end, chain_split() ? 1 : 0);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

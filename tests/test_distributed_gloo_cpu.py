@@ -36,6 +36,12 @@ def _problem(n, d, ns, seed=11):
 
 def _worker(rank, world, port, n, d, ns, out_dir, bcast="broadcast"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    # every rank is a process of its own on the same few cores: without a cap each one starts a BLAS / OpenMP pool as wide as the
+    # machine (8 ranks x 8 threads on 8 cores took 5 minutes for n = 4200)
+    threads = max(1, (os.cpu_count() or 1) // world)
+    torch.set_num_threads(threads)
+    from threadpoolctl import threadpool_limits
+    threadpool_limits(threads)
     if bcast == "whole_panel":                               # the unpipelined exchange: factor the panel, then one broadcast
         os.environ["GPRC_PIPE_BCAST"] = "0"
         bcast = "broadcast"
@@ -76,13 +82,15 @@ def _worker(rank, world, port, n, d, ns, out_dir, bcast="broadcast"):
                                            (4, 2100, "scatter_allgather"), (2, 1300, "auto"), (4, 700, "broadcast"),
                                            (2, 1300, "whole_panel"), (4, 3100, "scatter_allgather"), (3, 3100, "whole_panel"),
                                            (8, 4200, "broadcast"), (8, 4200, "scatter_allgather")])
-def test_block_cyclic_fit_and_sliced_predict(tmp_path, world, n, bcast):
+def test_block_cyclic_fit_and_sliced_predict(tmp_path, monkeypatch, world, n, bcast):
     """bcast: how a factored panel reaches the other ranks -- one rooted broadcast, or scatter + all-gather (the
     large-message form for point-to-point links); "auto" runs the calibration that picks one.  Same results.
     world = 8, n = 4200: the rank count BASELINE.json config 4 is quoted on (9 panels: rank 0 owns two, the others one)."""
     from oracle import oracle as orc
     d, ns = 3, (3 if n < 1000 else 37)   # n = 700: 2 panels and 3 test points on 4 ranks -- ranks that own nothing
     port = _free_port()
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):   # read when the children load their libraries
+        monkeypatch.setenv(var, str(max(1, (os.cpu_count() or 1) // world)))
     mp.spawn(_worker, args=(world, port, n, d, ns, str(tmp_path), bcast), nprocs=world, join=True)
     X, y, Xs = _problem(n, d, ns)
     ref = orc.gpr_fit(orc.SQREXP, [1.0], X.T, y, 0.1)
