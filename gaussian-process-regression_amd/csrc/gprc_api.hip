@@ -380,7 +380,7 @@ int factor_group_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* w
   if (per_panel) {
     for (int64_t p = g0; p + 1 < g1; ++p) GPRC_TRY(launch_trailing_service(s, packed, n_pad, p, winv, info_dev, sync, trace, g1));
   } else {
-    GPRC_TRY(launch_trailing_sweep(s, packed, n_pad, g0, g1, winv, info_dev, sync, trace, service_workgroups(service_carries_inverse(n_pad) && inv)));
+    GPRC_TRY(launch_trailing_sweep(s, packed, n_pad, g0, g1, winv, info_dev, sync, trace, service_workgroups(service_carries_inverse(n_pad) && inv, n_pad)));
   }
   GPRC_TRY(stream_after(ctx, s, side));
   return 0;

@@ -116,7 +116,7 @@ int launch_panel_strips(hipStream_t s, double* packed, int64_t n_pad, int64_t p,
 int launch_trailing_service(hipStream_t s, double* packed, int64_t n_pad, int64_t p, double* winv, int* info_dev, void* sync, void* trace, int64_t q_end);
 int launch_trailing_sweep(hipStream_t s, double* packed, int64_t n_pad, int64_t g0, int64_t g1, double* winv, int* info_dev, void* sync, void* trace,
                           int service_wgs);
-int service_workgroups(bool with_inverse);
+int service_workgroups(bool with_inverse, int64_t n_pad);
 std::string wait_timeout_report();   // who gave up first in the last timed-out factorisation (kernels_chol.hip), "" if nobody
 
 // ---- launchers (kernels_vec.hip) ---------------------------------------------------------------

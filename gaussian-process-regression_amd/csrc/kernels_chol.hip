@@ -1078,18 +1078,24 @@ constexpr unsigned long long WAIT_LIMIT_TICKS = 400000000ULL;   // 4 s
 //  the service's workgroups do not start together (another context's kernels on the GPU): profiles/r03_la_counter_race.txt.
 //  A strip goes through its blocks in order, so field TPP - 1 = TPP -- LA >= TPP << 24 -- means rows [NB, 2 NB) are final;
 //  E[0], E[1]: blocks (s, j <= s-2) the diagonal strips s = 2, 3 have finished;
-//  SU: the split chain's counters, eight 4-bit fields -- field j: 32-row slices of L(j, j-1) that are final (the chain helpers' solve
-//  phase), field 4 + j: slices of block (j, j) that have received L(j, j-1) (their update phase); each reaches CHAIN_HELPERS)
+//  SU: the split chain's counters, eight 4-bit fields with 3-bit counts -- field j: 32-row slices of L(j, j-1) that are final (the chain
+//  helpers' solve phase), field 4 + j: slices of block (j, j) that have received L(j, j-1) (their update phase); each reaches
+//  CHAIN_HELPERS.  j = 0 stands for the step BEHIND the panel: slices of L(4, 3), and of tile (0, 0) of the next diagonal block; bit 3 of
+//  field 0: that tile has received the k-chunks 0..2 (role SERVICE_D0).  R[0]: block (4, 3) is ready for its solve (look-ahead strip 4))
 
-// Who gave up, and on what: the FIRST wait of a factorisation that runs out its bound leaves a record for the host's error message
-// (wait_timeout_report) -- [0] site (1 flag, 2 count, 3 field, 4 chain, 5 sweep, 6 gate), [1] blockIdx.x, [2] gridDim.x,
-// [3] the value needed, [4] the value seen, [5] the awaited word's index inside its panel's PanelSync (or its distance from it),
-// [6] threads per workgroup
-__device__ int g_wait_diag[8];
+// Who gave up, and on what: every wait of a factorisation that runs out its bound -- and every wait that was still unsatisfied when it
+// saw that somebody else had (site + 10) -- leaves a record for the host (wait_timeout_report, gprc_debug_wait_timeout): up to
+// WAIT_DIAG_RECORDS records of 8 ints behind a counter -- [0] site (1 flag, 2 count, 3 field, 4 chain, 5 sweep, 6 gate), [1] blockIdx.x,
+// [2] gridDim.x, [3] the value needed, [4] the value seen, [5] the awaited word's index inside its panel's PanelSync (or its distance
+// from it), [6] threads per workgroup, [7] low 32 bits of the PanelSync's address (which panel)
+constexpr int WAIT_DIAG_RECORDS = 48;
+__device__ int g_wait_diag[8 * (WAIT_DIAG_RECORDS + 1)];
 __device__ __attribute__((noinline)) void wait_diag(int site, int need, int seen, const int* word, const void* sy) {
-  if (atomicCAS(&g_wait_diag[0], 0, site) != 0) return;
-  g_wait_diag[1] = (int)blockIdx.x; g_wait_diag[2] = (int)gridDim.x; g_wait_diag[3] = need; g_wait_diag[4] = seen;
-  g_wait_diag[5] = sy ? (int)(word - static_cast<const int*>(sy)) : -1; g_wait_diag[6] = (int)blockDim.x;
+  const int k = atomicAdd(&g_wait_diag[0], 1);
+  if (k >= WAIT_DIAG_RECORDS) return;
+  int* r = g_wait_diag + 8 * (k + 1);
+  r[0] = site; r[1] = (int)blockIdx.x; r[2] = (int)gridDim.x; r[3] = need; r[4] = seen;
+  r[5] = sy ? (int)(word - static_cast<const int*>(sy)) : -1; r[6] = (int)blockDim.x; r[7] = (int)(uintptr_t)sy;
 }
 
 // relaxed: the caller is throughput work (a strip riding in the sweep kernel), not a role of the chain: it looks at the flag once per
@@ -1111,7 +1117,7 @@ __device__ __forceinline__ void panel_flag_wait(int* flag, PanelSync* sy, int* i
       if ((++spins & 255) != 0) continue;
       // somebody has already given up (e.g. a profiler that serialises dispatches keeps producer and consumer kernels apart): every
       // later wait of the factorisation returns at once instead of running out its own bound
-      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
+      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) { wait_diag(11, 1, 0, flag, sy); break; }
       // exit condition every wave reaches (a producer that never publishes must not leave this workgroup spinning on the GPU
       // for ever): after WAIT_LIMIT_TICKS of wall time give up, let the grid drain, and tell the host through the ONE word it
       // always reads after a factorisation -- info = GPRC_INFO_WAIT_TIMEOUT (< 0; LAPACK infos are > 0)
@@ -1146,7 +1152,10 @@ __device__ __forceinline__ void panel_ready_wait(int* ctr, int need, PanelSync* 
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
       poll_pause(relaxed);
       if ((++spins & 255) != 0) continue;
-      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
+      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) {
+        wait_diag(12, need, __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ctr, sy);
+        break;
+      }
       if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) {   // bounded in wall time (see panel_flag_wait)
         wait_diag(2, need, __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ctr, sy);
         __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1169,7 +1178,10 @@ __device__ __forceinline__ void panel_field_wait(int* ctr, int shift, int need, 
     while (((__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> shift) & 0xff) < need) {
       __builtin_amdgcn_s_sleep(2);
       if ((++spins & 255) != 0) continue;
-      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
+      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) {
+        wait_diag(13, need << shift, __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ctr, sy);
+        break;
+      }
       if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) {   // bounded in wall time (see panel_flag_wait)
         wait_diag(3, need << shift, __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ctr, sy);
         __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1217,8 +1229,9 @@ constexpr int GPRC_CHAIN_PROF_PANEL = GPRC_CHAIN_PROF;
 constexpr int GPRC_CHAIN_PROF_PANEL = -1;
 #endif
 constexpr int CHAIN_HELPERS = 4;                  // 32-row slices of a 128-row block
+constexpr int PANEL_DIAG_TILES = TPP * (TPP + 1) / 2;   // lower 128 x 128 tiles of a panel's diagonal block
 constexpr int CHAIN_LDS_LD = 48;                  // doubles per k-slice of the A image: 32 rows + 16 pad (consecutive k-slices 32 banks apart)
-static_assert(CHAIN_HELPERS * 32 == 128 && CHAIN_HELPERS < 16, "SU holds 4-bit counts of 32-row slices");
+static_assert(CHAIN_HELPERS * 32 == 128 && CHAIN_HELPERS < 8, "SU holds 3-bit counts of 32-row slices (bit 3 of field 0 is a flag)");
 
 #ifdef GPRC_CHAIN_PROF
 // measurement build: s_memrealtime stamps (100 MHz) of panel GPRC_CHAIN_PROF's chain -- [0..31] helper 0 (8 per sub-step: W seen,
@@ -1230,22 +1243,26 @@ __device__ unsigned long long g_chain_prof[64];
 #define CHAIN_STAMP(on, k)
 #endif
 
-// waits until ((*a >> sa) & ma) >= va and (b == null or *b >= vb); the whole workgroup calls it; the polls fly together
-__device__ __forceinline__ void chain_wait2(int* a, int sa, int ma, int va, int* b, int vb, PanelSync* sy, int* info) {
+// waits until ((*a >> sa) & ma) >= va and (b == null or ((*b >> sb) & mb) >= vb); the whole workgroup calls it; the polls fly together
+__device__ __forceinline__ void chain_wait2(int* a, int sa, int ma, int va, int* b, int sb, int mb, int vb, PanelSync* sy, int* info) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (threadIdx.x == 0) {
     int spins = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
       const int xa = (__hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> sa) & ma;
-      const int xb = b ? __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : vb;
+      const int xb = b ? (__hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> sb) & mb : vb;
       if (xa >= va && xb >= vb) break;
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 255) != 0) continue;
-      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) break;
+      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) {
+        if (xa < va) wait_diag(14, va << sa, __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a, sy);
+        else wait_diag(14, vb << sb, __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b, sy);
+        break;
+      }
       if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) {   // bounded in wall time (see panel_flag_wait)
         if (xa < va) wait_diag(4, va << sa, __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a, sy);
-        else wait_diag(4, vb, xb, b, sy);
+        else wait_diag(4, vb << sb, __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b, sy);
         __hip_atomic_store(&sy->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicExch(info, GPRC_INFO_WAIT_TIMEOUT);
         break;
@@ -1333,22 +1350,31 @@ __device__ __forceinline__ int chain_publish(int* ctr, int add) {
 // down from 38 to 17 us the chain waited 29 us for strip 3's K = 256 tiles, tools/chain_prof.py).  A helper touches only its own 32
 // rows of those blocks, k-chunk after k-chunk in order: no flag between them, and the same accumulator chain through memory.
 // strip_progress: E[0] / E[1], the finished blocks (s, j <= s-2) of the diagonal strips s = 2, 3.
+// dnext (null: no next panel in the launch's group): tile (0, 0) of the NEXT panel's diagonal block, leading dimension ldn.  The path from
+// W_3 to the next chain is the same pattern once more -- L(4, 3) = C'(4, 3) Winv_3^T, D(0, 0) -= L(4, 3) L(4, 3)^T, potf2 -- and was a
+// 17-us solve on the look-ahead strip's CU plus a 20-us tile on a next-diagonal-block role's; the helpers do both in slices: the
+// look-ahead strip TPP hands block (4, 3) over when it has received the panel's earlier columns (R[0]), role SERVICE_D0 hands tile
+// (0, 0) over when it has received the k-chunks 0..2 (bit 3 of SU), the last solve slice counts the
+// block into LA for that strip, the last update slice counts the tile into ready_next, and the next factor role starts on the
+// update slices' count (field 4 of SU) instead of waiting for the other nine tiles, which it does not read.
+// ready_mine (null: first panel of the launch): the count of finished tiles of THIS panel's diagonal block -- the helpers' first solve
+// reads tile (1, 0), which the factor role no longer waits for.
 __device__ __attribute__((noinline)) void panel_chain_helper_role(double* sm, double* pan, int64_t ld, double* wp, int* info, PanelSync* sy, int q,
-                                                                  bool prof) {
+                                                                  bool prof, double* dnext, int64_t ldn, int* ready_next, int* ready_mine) {
   for (int j = 0; j + 1 < TPP; ++j) {
     double* Cn = pan + (int64_t)(j + 1) * NBI + (int64_t)j * NBI * ld;            // block (j+1, j)
     double* Dn = pan + (int64_t)(j + 1) * NBI + (int64_t)(j + 1) * NBI * ld;      // block (j+1, j+1)
     const int fs = 4 * (j + 1), fu = 16 + 4 * (j + 1);
     // solve: W_j published; j > 0: block (j+1, j) has received the columns left of block j (E = 1, the diagonal strip j+1)
-    chain_wait2(&sy->W[j], 0, 1, 1, j > 0 ? &sy->E[j + 1] : nullptr, 1, sy, info);
+    chain_wait2(&sy->W[j], 0, 1, 1, j > 0 ? &sy->E[j + 1] : ready_mine, 0, 0xffff, j > 0 ? 1 : PANEL_DIAG_TILES, sy, info);
     CHAIN_STAMP(prof, 8 * j);
     chain_slice_32<true>(Cn + 32 * q, ld, Cn + 32 * q, ld, wp + (int64_t)j * NBI * NBI, 128, sm, prof, 8 * j + 1);
     const int before = chain_publish(&sy->SU, 1 << fs);
     CHAIN_STAMP(prof, 8 * j + 3);
     // the last slice completes L(j+1, j): R_{j+1} for the strips (every slice was written through and had landed before its count)
-    if (threadIdx.x == 0 && ((before >> fs) & 15) == CHAIN_HELPERS - 1) __hip_atomic_store(&sy->R[j + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && ((before >> fs) & 7) == CHAIN_HELPERS - 1) __hip_atomic_store(&sy->R[j + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // update: all four slices of L(j+1, j)
-    chain_wait2(&sy->SU, fs, 15, CHAIN_HELPERS, nullptr, 0, sy, info);
+    chain_wait2(&sy->SU, fs, 7, CHAIN_HELPERS, nullptr, 0, 0, 0, sy, info);
     CHAIN_STAMP(prof, 8 * j + 4);
     chain_slice_32<false>(Dn + 32 * q, ld, Cn + 32 * q, ld, Cn, ld, sm, prof, 8 * j + 5);
     (void)chain_publish(&sy->SU, 1 << fu);
@@ -1356,16 +1382,31 @@ __device__ __attribute__((noinline)) void panel_chain_helper_role(double* sm, do
     // while the factor role is busy with block (j+1, j+1): column j into the later diagonal blocks
     for (int s = j + 2; s < TPP; ++s) {
       double* Ls = pan + (int64_t)s * NBI + (int64_t)j * NBI * ld;                // L(s, j), solved by diagonal strip s
-      chain_wait2(&sy->E[s - 2], 0, 0xffff, j + 1, nullptr, 0, sy, info);
+      chain_wait2(&sy->E[s - 2], 0, 0xffff, j + 1, nullptr, 0, 0, 0, sy, info);
       chain_slice_32<false>(pan + (int64_t)s * NBI + (int64_t)s * NBI * ld + 32 * q, ld, Ls + 32 * q, ld, Ls, ld, sm);
     }
+  }
+  if (dnext) {
+    double* Cn = pan + (int64_t)TPP * NBI + (int64_t)(TPP - 1) * NBI * ld;       // block (4, 3)
+    chain_wait2(&sy->W[TPP - 1], 0, 1, 1, &sy->R[0], 0, 1, 1, sy, info);
+    CHAIN_STAMP(prof, 24);
+    chain_slice_32<true>(Cn + 32 * q, ld, Cn + 32 * q, ld, wp + (int64_t)(TPP - 1) * NBI * NBI, 128, sm, prof, 25);
+    const int b0 = chain_publish(&sy->SU, 1);
+    CHAIN_STAMP(prof, 27);
+    if (threadIdx.x == 0 && (b0 & 7) == CHAIN_HELPERS - 1) __hip_atomic_fetch_add(&sy->LA, 1 << (8 * (TPP - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    chain_wait2(&sy->SU, 0, 7, CHAIN_HELPERS, &sy->SU, 3, 1, 1, sy, info);   // all slices of L(4, 3); tile (0, 0) has its k-chunks 0..2 (bit 3)
+    CHAIN_STAMP(prof, 28);
+    chain_slice_32<false>(dnext + 32 * q, ldn, Cn + 32 * q, ld, Cn, ld, sm, prof, 29);
+    const int b1 = chain_publish(&sy->SU, 1 << 16);
+    CHAIN_STAMP(prof, 31);
+    if (threadIdx.x == 0 && ((b1 >> 16) & 7) == CHAIN_HELPERS - 1) __hip_atomic_fetch_add(ready_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 // The factor role beside the chain helpers: the four diagonal blocks, each loaded when its update slices are complete.
 __device__ __forceinline__ void panel_factor_role_split(double* sm, double* pan, int64_t ld, double* wp, int* info, int p, PanelSync* sy) {
   for (int j = 0; j < TPP; ++j) {
-    if (j > 0) chain_wait2(&sy->SU, 16 + 4 * j, 15, CHAIN_HELPERS, nullptr, 0, sy, info);
+    if (j > 0) chain_wait2(&sy->SU, 16 + 4 * j, 7, CHAIN_HELPERS, nullptr, 0, 0, 0, sy, info);
     CHAIN_STAMP(p == GPRC_CHAIN_PROF_PANEL, 32 + 4 * j);
     potf2_blocked_body<8>(sm, pan + (int64_t)j * NBI + (int64_t)j * NBI * ld, ld, wp + (int64_t)j * NBI * NBI, info, p * NB + j * NBI, nullptr, false);
     CHAIN_STAMP(p == GPRC_CHAIN_PROF_PANEL, 33 + 4 * j);
@@ -1420,7 +1461,7 @@ __device__ __forceinline__ void panel_factor_role(double* sm, double* pan, int64
 // progress_shift: the count of block (s, j) goes to the 8-bit field j of *progress (teams << progress_shift j; 0: one plain sum).
 __device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int64_t ld, double* wp, int* info, PanelSync* sy, int s, int tid,
                                                  int* progress = nullptr, int teams = 1, int* early = nullptr, int progress_shift = 0, bool relaxed = false,
-                                                 bool skip_diag = false) {
+                                                 bool skip_diag = false, bool hand_last = false, int* early_done = nullptr) {
   if (s < 2) return;
   const double* Arow = pan + (int64_t)s * 128;     // my 128 rows of the panel
   const int jlast = s < TPP ? s - 2 : TPP - 1;     // a diagonal strip solves blocks (s, 0..s-2) itself
@@ -1431,14 +1472,22 @@ __device__ __forceinline__ void panel_strip_role(double* smem, double* pan, int6
     if (j > 0) {
       if (early && j >= 2) {
         const int64_t ke = (int64_t)(j - 1) * NBI;
-        panel_ready_wait(&early[j - 2], j - 1, sy, info, relaxed);   // L(j, 0..j-2) final
-        gemm_tile_128<false, false, false, false, false, false>(C, ld, Arow, ld, pan + cj, ld, (int)ke, smem, 0, 0, 0, nullptr, tid);
+        if (early_done) {                                   // split chain: a next-diagonal-block role has applied the early chunks (panel_next_diag_role)
+          panel_flag_wait(&early_done[(j - 2) * TPP], sy, info, relaxed);
+        } else {
+          panel_ready_wait(&early[j - 2], j - 1, sy, info, relaxed);   // L(j, 0..j-2) final
+          gemm_tile_128<false, false, false, false, false, false>(C, ld, Arow, ld, pan + cj, ld, (int)ke, smem, 0, 0, 0, nullptr, tid);
+        }
         panel_flag_wait(&sy->R[j], sy, info, relaxed);      // (its vmcnt(0) + barrier: the block is reloaded as the next call's C)
         gemm_tile_128<false, false, false, false, false, false>(C, ld, Arow + ke * ld, ld, pan + cj + ke * ld, ld, 128, smem, 0, 0, 0, nullptr, tid);
       } else {
         panel_flag_wait(&sy->R[j], sy, info, relaxed);      // rows of strip j left of its diagonal block are final
         gemm_tile_128<false, false, false, false, false, false>(C, ld, Arow, ld, pan + cj, ld, (int)cj, smem, 0, 0, 0, nullptr, tid);
       }
+    }
+    if (hand_last && j == TPP - 1) {               // split chain, look-ahead strip TPP: the chain helpers solve this block (R[0]: it is ready for them)
+      panel_flag_publish(&sy->R[0]);
+      break;
     }
     panel_flag_wait(&sy->W[j], sy, info, relaxed);
     gemm_tile_128<true, false, false, false, false, false>(C, ld, C, ld, wp + (int64_t)j * NBI * NBI, 128, 128, smem, 0, 0, 0, nullptr, tid);
@@ -1562,7 +1611,6 @@ __global__ __launch_bounds__(256, 2) void inv512_kernel(const double* packed, in
 // update of panel p - 1, which waits only on service flags of panel p - 1; and nothing that waits on the service is launched before
 // the service is resident (service_gate_kernel, the first kernel on the caller's stream).
 // ------------------------------------------------------------------------------------------------
-constexpr int PANEL_DIAG_TILES = TPP * (TPP + 1) / 2;
 constexpr int PANEL_LA_TILES = TPP * TPP;             // tiles of a panel's rows [NB, 2 NB)
 constexpr int SERVICE_LA0 = 3;                                   // first look-ahead strip role (one 4-wave team per workgroup)
 constexpr int SERVICE_D0 = SERVICE_LA0 + TPP;                    // first next-diagonal-block role (one tile per workgroup)
@@ -1572,18 +1620,39 @@ constexpr int SERVICE_WGS = SERVICE_H0 + CHAIN_HELPERS;
 
 // One team's share of the next diagonal block: lower tile `idx` (0..9: (0,0) (1,0) (1,1) (2,0) ...) of the block, in four k-chunks.
 __device__ __forceinline__ void panel_next_diag_role(double* smem, const double* pan, int64_t ld, double* Dn, int64_t ldn, int* info,
-                                                     PanelSync* sy, int idx, int tid, unsigned long long* stamp) {
+                                                     PanelSync* sy, int idx, int tid, unsigned long long* stamp, bool hand_last = false,
+                                                     int* aux = nullptr) {
   int tr = 0;
   while ((tr + 1) * (tr + 2) / 2 <= idx) ++tr;
   const int tc = idx - tr * (tr + 1) / 2;
   double* C = Dn + (int64_t)tr * 128 + (int64_t)tc * 128 * ldn;
+  // aux (split chain; null otherwise): this role also applies, between its own k-chunks, the EARLY k-chunks of one look-ahead strip's
+  // block -- with the chain down to ~200 us a look-ahead strip's ten tiles (~220 us on its one CU) had become the bound
+  // (tools/chain_prof.py), while these roles are busy 80 us per panel.  idx 1..4: block (s, 2), s = 3 + idx, chunk 0 after the role's own
+  // chunk 0; idx 5..8: block (s, 3), s = idx - 1, chunk 0 there and chunk 1 after the role's chunk 1.  aux[s - TPP] / aux[TPP + s - TPP]
+  // = 1: the block has its early chunks (the strip applies the last one).  Same products in the same order, continued through memory.
+  const int es = !aux ? -1 : (idx >= 1 && idx <= TPP) ? TPP - 1 + idx : (idx > TPP && idx <= 2 * TPP) ? idx - 1 : -1;   // my look-ahead strip
+  const int eb = idx <= TPP ? 2 : 3;                                                                                    // ... and its block
   for (int j = 0; j < TPP; ++j) {
+    if (hand_last && j == TPP - 1) {                   // split chain, tile (0, 0): the chain helpers apply the last k-chunk (bit 3 of SU: the tile is ready for them)
+      panel_count_publish(&sy->SU, 8);
+      break;
+    }
     panel_field_wait(&sy->LA, 8 * j, TPP, sy, info);   // all four look-ahead strips have finished sub-step j
     if (stamp && j == TPP - 1 && threadIdx.x == 0) *stamp = __builtin_amdgcn_s_memrealtime();
     gemm_tile_128<false, false, false, false, false, false>(C, ldn, pan + (int64_t)(TPP + tr) * 128 + (int64_t)j * NBI * ld, ld, pan + (int64_t)(TPP + tc) * 128 + (int64_t)j * NBI * ld, ld,
                          128, smem, 0, 0, 0, nullptr, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile is reloaded as the next chunk's C
     __syncthreads();
+    if (es >= 0 && j <= eb - 2) {                      // L(es, j) is final (LA field j); L(eb, j): the diagonal strip eb's progress
+      panel_ready_wait(&sy->E[eb - 2], j + 1, sy, info);
+      double* Ce = const_cast<double*>(pan) + (int64_t)es * 128 + (int64_t)eb * NBI * ld;
+      gemm_tile_128<false, false, false, false, false, false>(Ce, ld, pan + (int64_t)es * 128 + (int64_t)j * NBI * ld, ld, pan + (int64_t)eb * NBI + (int64_t)j * NBI * ld, ld,
+                           128, smem, 0, 0, 0, nullptr, tid);
+      if (j == eb - 2) panel_flag_publish(&aux[(eb - 2) * TPP + es - TPP]);
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 }
 
@@ -1610,9 +1679,15 @@ __global__ __launch_bounds__(512) void panel_service_kernel(double* packed, int6
     const int64_t ld = panel_ld(n_pad, p);
     double* pan = packed + panel_offset(n_pad, p);
     double* wp = winv + (int64_t)p * TPP * NBI * NBI;
+    const bool hand = split && p + 1 < p_end;        // the path W_3 -> next chain goes through the chain helpers
+    // aux[p][2 TPP]: flags "block (TPP + i, 2) / (TPP + i, 3) of panel p has its early k-chunks", behind the sweep kernel's flags in the sync block
+    int* aux = ready + 3 * P + 16 + 2 * P * TPP * P + 8 * P + P * TPP * P * TPP + (int64_t)p * 2 * TPP;
     if (role <= 2) {
       if (role == 0) SERVICE_STAMP(p, 14);
-      if (p > p_begin) panel_ready_wait(&ready[p], PANEL_DIAG_TILES, sy, info);
+      if (p > p_begin) {
+        if (role == 0 && split) chain_wait2(&sy_base[p - 1].SU, 16, 7, CHAIN_HELPERS, nullptr, 0, 0, 0, sy, info);   // tile (0, 0) is all the first potf2 reads
+        else panel_ready_wait(&ready[p], PANEL_DIAG_TILES, sy, info);
+      }
       if (role == 0) SERVICE_STAMP(p, 0);
       if (role == 0) {
         if (split) panel_factor_role_split(sm, pan, ld, wp, info, p, sy);
@@ -1620,21 +1695,24 @@ __global__ __launch_bounds__(512) void panel_service_kernel(double* packed, int6
       } else panel_strip_role(sm, pan, ld, wp, info, sy, role + 1, tid, &sy->E[role - 1], 1, nullptr, 0, false, split != 0);
       if (role == 0) SERVICE_STAMP(p, 1);
     } else if (role >= SERVICE_H0) {
-      panel_chain_helper_role(sm, pan, ld, wp, info, sy, role - SERVICE_H0, role == SERVICE_H0 && p == GPRC_CHAIN_PROF_PANEL);   // paced by this panel's W flags
+      panel_chain_helper_role(sm, pan, ld, wp, info, sy, role - SERVICE_H0, role == SERVICE_H0 && p == GPRC_CHAIN_PROF_PANEL,   // paced by this panel's W flags
+                              hand ? packed + panel_offset(n_pad, p + 1) : nullptr, hand ? panel_ld(n_pad, p + 1) : 0, &ready[p + 1],
+                              p > p_begin ? &ready[p] : nullptr);
     } else if (role >= SERVICE_INV0) {
       inv512_row_role(sm, pan, ld, wp, inv + (int64_t)p * NB * NB, role - SERVICE_INV0, tid, sy, info);
     } else if (role < SERVICE_D0 ? p + 1 < P : p + 1 < p_end) {
       if (role < SERVICE_D0) {
         if (p > p_begin) panel_ready_wait(&ready[P + p], PANEL_LA_TILES, sy, info);
         if (role == SERVICE_LA0) SERVICE_STAMP(p, 2);
-        panel_strip_role(sm, pan, ld, wp, info, sy, TPP + (role - SERVICE_LA0), tid, &sy->LA, 1, sy->E, 8);
+        panel_strip_role(sm, pan, ld, wp, info, sy, TPP + (role - SERVICE_LA0), tid, &sy->LA, 1, sy->E, 8, false, false, hand && role == SERVICE_LA0,
+                         hand ? aux + (role - SERVICE_LA0) : nullptr);
         if (role == SERVICE_LA0) SERVICE_STAMP(p, 3);
       } else {
         if (p > p_begin) panel_ready_wait(&ready[2 * P + p + 1], PANEL_DIAG_TILES, sy, info);
         if (role == SERVICE_D0) SERVICE_STAMP(p, 4);
         panel_next_diag_role(sm, pan, ld, packed + panel_offset(n_pad, p + 1), panel_ld(n_pad, p + 1), info, sy, role - SERVICE_D0, tid,
-                             (role == SERVICE_D0 && trace) ? trace + 16 * p + 5 : nullptr);
-        panel_count_publish(&ready[p + 1], 1);
+                             (role == SERVICE_D0 && trace) ? trace + 16 * p + 5 : nullptr, hand && role == SERVICE_D0, hand ? aux : nullptr);
+        if (!(hand && role == SERVICE_D0)) panel_count_publish(&ready[p + 1], 1);
         if (role == SERVICE_INV0 - 1) SERVICE_STAMP(p, 6);
       }
     }
@@ -1819,7 +1897,11 @@ __device__ __forceinline__ bool sweep_wait3(int* a, int va, int* b, int vb, int*
       if (xa >= va && xb >= vb && xc >= vc) break;
       poll_pause(true);
       if ((++spins & 63) != 1) continue;              // at the first miss and every 64th from there
-      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) { *sh_dead = 1; break; }
+      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GPRC_INFO_WAIT_TIMEOUT) {
+        if (xa < va) wait_diag(15, va, xa, a, failed - 1); else if (xb < vb) wait_diag(15, vb, xb, b, failed - 1); else wait_diag(15, vc, xc, c, failed - 1);
+        *sh_dead = 1;
+        break;
+      }
       if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) {   // bounded in wall time (see panel_flag_wait)
         if (xa < va) wait_diag(5, va, xa, a, failed - 1); else if (xb < vb) wait_diag(5, vb, xb, b, failed - 1); else wait_diag(5, vc, xc, c, failed - 1);
         __hip_atomic_store(failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2000,11 +2082,12 @@ __global__ __launch_bounds__(256, 2) void trailing_sweep_kernel(double* packed, 
 }
 }  // namespace
 }  // namespace gprc
-// tools only (not part of include/gprc_native.h): the raw record of the first timed-out wait, see wait_diag; clears it
-extern "C" __attribute__((visibility("default"))) int gprc_debug_wait_timeout(int* out8) {
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gprc::g_wait_diag), 32) != hipSuccess) return -1;
-  const int z[8] = {};
-  return hipMemcpyToSymbol(HIP_SYMBOL(gprc::g_wait_diag), z, 32) == hipSuccess ? 0 : -1;
+// tools only (not part of include/gprc_native.h): the raw records of the timed-out waits, see wait_diag; clears them
+extern "C" __attribute__((visibility("default"))) int gprc_debug_wait_timeout(int* out, int ints) {   // out[0]: records written; 8 ints per record from out[8]
+  const size_t bytes = sizeof(int) * (size_t)std::min(ints, 8 * (gprc::WAIT_DIAG_RECORDS + 1));
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gprc::g_wait_diag), bytes) != hipSuccess) return -1;
+  static const int z[8 * (gprc::WAIT_DIAG_RECORDS + 1)] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(gprc::g_wait_diag), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 namespace gprc {
 namespace {
@@ -2081,7 +2164,7 @@ static int ensure_gemm_attrs();
 // ... and behind them the persistent sweep's flags (trailing_sweep_kernel): stripdone[P][TPP P], rest_ticket[P][8], ver[P][TPP P][TPP]
 size_t panel_service_sync_bytes(int64_t P) {
   return (size_t)P * sizeof(PanelSync) + (3 * (size_t)P + 16) * sizeof(int) + (size_t)P * TPP * P * sizeof(int) +
-         ((size_t)P * TPP * P + 8 * (size_t)P + (size_t)P * TPP * P * TPP) * sizeof(int);
+         ((size_t)P * TPP * P + 8 * (size_t)P + (size_t)P * TPP * P * TPP) * sizeof(int) + (size_t)P * 2 * TPP * sizeof(int);   // ... and aux[P][2 TPP]
 }
 
 // sync: panel_service_sync_bytes(P) bytes of device memory, zeroed by the caller (stream-ordered before this launch)
@@ -2094,26 +2177,34 @@ int launch_inv512(hipStream_t s, const double* packed, int64_t n_pad, const doub
   return 0;
 }
 
-// GPRC_CHAIN_SPLIT=0 / 1: the factor role's two tiles per sub-step on its own CU / split over the four chain helpers
-bool chain_split() {
-  static const int v = [] { const char* e = std::getenv("GPRC_CHAIN_SPLIT"); return e ? std::atoi(e) : 0; }();
-  return v != 0;
+// The split chain (four more resident CUs) where the panel chain weighs: below n_pad = 20480, i.e. wherever the whole matrix is ONE group
+// of the service (measured, same box, profiles/r03_chain_split.txt; in the grouped schedule beyond it makes no difference and the four
+// CUs stay with the update).  GPRC_CHAIN_SPLIT=0 / 1 forces it off / on at every size.
+bool chain_split(int64_t n_pad) {
+  static const int v = [] { const char* e = std::getenv("GPRC_CHAIN_SPLIT"); return e ? std::atoi(e) : -1; }();
+  return v >= 0 ? v != 0 : n_pad < 20480;
 }
 
-// the record the first timed-out wait left (wait_diag), as text for the host's error message; clears it
+// the records the timed-out waits left (wait_diag), as text for the host's error message; clears them
 std::string wait_timeout_report() {
-  int v[8] = {};
+  static int v[8 * (WAIT_DIAG_RECORDS + 1)];
   if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_wait_diag), sizeof(v)) != hipSuccess || v[0] == 0) return "";
-  const int z[8] = {};
+  static const int z[8 * (WAIT_DIAG_RECORDS + 1)] = {};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wait_diag), z, sizeof(z));
   static const char* const site[] = {"?", "flag", "count", "field", "chain", "sweep", "gate"};
-  return std::string(" [first wait to give up: ") + site[v[0] >= 0 && v[0] <= 6 ? v[0] : 0] + " wait of workgroup " + std::to_string(v[1]) + " of " +
-         std::to_string(v[2]) + " x " + std::to_string(v[6]) + " threads, needed " + std::to_string(v[3]) + ", saw " + std::to_string(v[4]) +
-         ", word " + std::to_string(v[5]) + " of its panel's flags]";
+  std::string out = " [waits that gave up (+10: still waiting when somebody else had):";
+  const int n = v[0] < WAIT_DIAG_RECORDS ? v[0] : WAIT_DIAG_RECORDS;
+  for (int k = 0; k < n && k < 8; ++k) {
+    const int* r = v + 8 * (k + 1);
+    const int st = r[0] % 10;
+    out += std::string(k ? ";" : "") + " " + site[st >= 0 && st <= 6 ? st : 0] + (r[0] >= 10 ? "+10" : "") + " wait of workgroup " + std::to_string(r[1]) + "/" +
+           std::to_string(r[2]) + "x" + std::to_string(r[6]) + " needed " + std::to_string(r[3]) + " saw " + std::to_string(r[4]) + " word " + std::to_string(r[5]);
+  }
+  return out + (v[0] > 8 ? "; ... " + std::to_string(v[0]) + " in all]" : "]");
 }
 
 // workgroups the service keeps resident (a CU each)
-int service_workgroups(bool with_inverse) { return SERVICE_INV0 + (with_inverse ? TPP : 0) + (chain_split() ? CHAIN_HELPERS : 0); }
+int service_workgroups(bool with_inverse, int64_t n_pad) { return SERVICE_INV0 + (with_inverse ? TPP : 0) + (chain_split(n_pad) ? CHAIN_HELPERS : 0); }
 
 int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync, void* trace, double* inv,
                          int64_t p_begin, int64_t p_end) {
@@ -2130,7 +2221,7 @@ int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* w
   int* ready = reinterpret_cast<int*>(static_cast<char*>(sync) + (size_t)P * sizeof(PanelSync));
   ProfScope ps(s, PK_PANEL_FUSED, 0.0, 0.0);
   hipLaunchKernelGGL(panel_service_kernel, dim3(SERVICE_WGS), dim3(512), smem, s, packed, n_pad, winv, info_dev, sy, ready, (int)P,
-                     static_cast<unsigned long long*>(trace), inv, (int)p_begin, (int)p_end, chain_split() ? 1 : 0);
+                     static_cast<unsigned long long*>(trace), inv, (int)p_begin, (int)p_end, chain_split(n_pad) ? 1 : 0);
   GPRC_LAUNCH_CHECK();
   return 0;
 }

@@ -429,3 +429,44 @@ def test_one_launch_per_panel_under_the_service_is_still_bit_identical(tmp_path)
     env = dict(os.environ, GPRC_SWEEP="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "SWEEP0_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("env", [{"GPRC_CHAIN_SPLIT": "0"}, {"GPRC_CHAIN_SPLIT": "1", "GPRC_FACTOR": "40"}, {"GPRC_CHAIN_SPLIT": "1", "GPRC_SWEEP": "0"}],
+                         ids=["unsplit", "split-in-groups", "split-launch-per-panel"])
+def test_both_forms_of_the_panel_chain_are_bit_identical(env):
+    """The split chain (four helper workgroups share the chain's solve / update tiles in 32-row slices, apply every update of a panel's
+    diagonal blocks and run the step from W_3 to the next panel's first potf2; the look-ahead strips' early k-chunks ride on the
+    next-diagonal-block roles) is the default below n_pad = 20480.  GPRC_CHAIN_SPLIT is read once per process, so child processes
+    force the other form, the split form inside the groups of the left-looking schedule (GPRC_FACTOR=40: groups of a few panels, i.e.
+    group boundaries where the hand-over to the helpers does not happen) and the split form beside one update launch per panel -- each
+    compared word for word, with the explicit inverses, against the factor_panel / update_trailing sweep."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "import tests.test_gpu_device_level as t\n"
+        "from gprc_amd import _native as nat\n"
+        "for n in (1024, 2900, 9100):\n"
+        "    L, ctx, g, K = t._filled(n, seed=7)\n"
+        "    a = t._clone(K); w, info = t._new(g)\n"
+        "    for p in range(g.P):\n"
+        "        nat.check(L.gprc_dev_factor_panel(ctx.handle, a.data_ptr(), g.n_pad, p, w.data_ptr(), info.data_ptr()))\n"
+        "        if p + 1 < g.P:\n"
+        "            nat.check(L.gprc_dev_update_trailing(ctx.handle, a.data_ptr(), g.n_pad, p, p + 1, g.P, 1))\n"
+        "    inv = t._new_inv(g)\n"
+        "    nat.check(L.gprc_dev_solve_prepare(ctx.handle, a.data_ptr(), w.data_ptr(), g.n_pad, inv.data_ptr(), 0, g.P))\n"
+        "    torch.cuda.synchronize()\n"
+        "    for rep in range(3):\n"
+        "        b = t._clone(K); w2, info2 = t._new(g); inv2 = t._new_inv(g)\n"
+        "        nat.check(L.gprc_dev_factor_all(ctx.handle, b.data_ptr(), g.n_pad, w2.data_ptr(), info2.data_ptr(), inv2.data_ptr()))\n"
+        "        torch.cuda.synchronize()\n"
+        "        assert int(info[0]) == 0 and int(info2[0]) == 0, (n, int(info2[0]))\n"
+        "        assert torch.equal(b, a) and torch.equal(w2, w), n\n"
+        "        assert torch.equal(torch.nan_to_num(inv2), torch.nan_to_num(inv)), n   # (entries below the block diagonal are never written)\n"
+        "    ctx.close()\n"
+        "print('CHAIN_OK')\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "CHAIN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -33,7 +33,7 @@ for rep in range(4):
     v = np.array(list(out), dtype=np.int64)
     t0 = v[34]                      # W_0 published
     ev = [(v[32 + 4 * j + k], f"factor j={j} " + ["U seen", "potf2 done", "W published"][k]) for j in range(4) for k in range(3)]
-    ev += [(v[8 * j + k], f"  helper j={j} " + names[k]) for j in range(3) for k in range(8)]
+    ev += [(v[8 * j + k], f"  helper j={j} " + names[k]) for j in range(4) for k in range(8) if v[8 * j + k]]
     ev.sort()
     print(f"rep {rep}")
     prev = None

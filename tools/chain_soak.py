@@ -35,8 +35,9 @@ for r in range(rounds):
         torch.cuda.synchronize()
         count += 1
         if int(info[0]) < 0:
-            rec = (ctypes.c_int * 8)(); L.gprc_debug_wait_timeout(rec)
-            print(f"round {r} n={n}: info={int(info[0])}; first wait to give up [site, workgroup, grid, needed, saw, word, threads]: {list(rec)[:7]}", flush=True)
+            rec = (ctypes.c_int * 392)(); L.gprc_debug_wait_timeout(rec, 392)
+            print(f"round {r} n={n}: info={int(info[0])}; waits that gave up [site (+10: bystander), workgroup, grid, needed, saw, word, threads, sy]:", flush=True)
+            for k in range(min(rec[0], 48)): print("   ", list(rec)[8 * (k + 1): 8 * (k + 2)], flush=True)
             sys.exit(3)
         assert int(info[0]) == 0, int(info[0])
         if st["ref"] is None:
