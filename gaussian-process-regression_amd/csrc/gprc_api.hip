@@ -82,6 +82,7 @@ struct gprc_ctx {
                                // + another 64 for launches on the look-ahead stream
   // the factor service's persistent launch runs on a high-priority side stream beside the caller's kernels (factor_group_service)
   hipStream_t side_stream = nullptr;
+  hipStream_t side_stream2 = nullptr;  // the shared service's second launch (the 4-wave roles) runs beside the first
   void* svc_trace = nullptr;          // GPRC_SERVICE_TRACE: 16 stamps x SVC_TRACE_PANELS of the last factor-service sweep (measurement)
   hipEvent_t ev_pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned ev_next = 0;
@@ -367,6 +368,13 @@ int factor_group_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* w
   // The explicit inverses ride in the service (four more resident workgroups, off the chain) below n_pad = 20480, where the whole
   // matrix is one group; in the grouped schedule beyond, one launch after the sweep computes them (factor_all_async) and the four
   // CUs go to the update.
+  const bool shared = service_shared(n_pad);
+  if (shared) {
+    hipStream_t side2 = ctx->side_stream2;
+    GPRC_TRY(stream_after(ctx, side2, s));
+    GPRC_TRY(launch_panel_service(side, packed, n_pad, winv, info_dev, sync, trace, service_carries_inverse(n_pad) ? inv : nullptr, g0, g1, 1));
+    GPRC_TRY(launch_panel_service(side2, packed, n_pad, winv, info_dev, sync, trace, service_carries_inverse(n_pad) ? inv : nullptr, g0, g1, 2));
+  } else
   GPRC_TRY(launch_panel_service(side, packed, n_pad, winv, info_dev, sync, trace, service_carries_inverse(n_pad) ? inv : nullptr, g0, g1));
   GPRC_TRY(launch_service_gate(s, n_pad, info_dev, sync, launches));   // nothing that waits on the service starts before the service is resident
   GPRC_TRY(launch_panel_strips(s, packed, n_pad, g0, winv, info_dev, sync, trace));        // the later panels' strips ride in the update kernels
@@ -383,6 +391,7 @@ int factor_group_service(gprc_ctx* ctx, double* packed, int64_t n_pad, double* w
     GPRC_TRY(launch_trailing_sweep(s, packed, n_pad, g0, g1, winv, info_dev, sync, trace, service_workgroups(service_carries_inverse(n_pad) && inv, n_pad)));
   }
   GPRC_TRY(stream_after(ctx, s, side));
+  if (shared) GPRC_TRY(stream_after(ctx, s, ctx->side_stream2));
   return 0;
 }
 
@@ -411,6 +420,7 @@ int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv,
       int lo = 0, hi = 0;
       GPRC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
       GPRC_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi));
+      GPRC_HIP(hipStreamCreateWithPriority(&ctx->side_stream2, hipStreamNonBlocking, hi));
     }
     GPRC_TRY(sync.alloc((int64_t)(panel_service_sync_bytes(P) + 7) / 8));
     GPRC_HIP(hipMemsetAsync(sync.p, 0, panel_service_sync_bytes(P), s));
@@ -444,6 +454,7 @@ int factor_all_async(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv,
     // a launch failed half way: the persistent service kernel may still be running on the side stream and spinning on the flags in
     // `sync` (its waits are bounded).  The block must not go back to the pool -- to be handed to somebody else -- before it has left.
     (void)hipStreamSynchronize(ctx->side_stream);
+    if (ctx->side_stream2) (void)hipStreamSynchronize(ctx->side_stream2);
     (void)hipStreamSynchronize(s);
   }
   return rc;
@@ -847,6 +858,7 @@ int gprc_ctx_destroy(gprc_ctx* ctx) {
   if (ctx->sync_dev) (void)hipFree(ctx->sync_dev);
   if (ctx->svc_trace) (void)hipFree(ctx->svc_trace);
   if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+  if (ctx->side_stream2) { (void)hipStreamSynchronize(ctx->side_stream2); (void)hipStreamDestroy(ctx->side_stream2); }
   for (hipEvent_t ev : ctx->ev_pool)
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

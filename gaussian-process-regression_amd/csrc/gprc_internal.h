@@ -108,7 +108,8 @@ int launch_trailing_update(hipStream_t s, double* packed, int64_t n_pad, int64_t
 // the ordinary strips and the trailing update without the next diagonal block (caller's stream)
 size_t panel_service_sync_bytes(int64_t P);
 int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync, void* trace, double* inv,
-                         int64_t p_begin, int64_t p_end);
+                         int64_t p_begin, int64_t p_end, int part = 0);
+bool service_shared(int64_t n_pad);   // the service's 4-wave roles share their CUs with one sweep workgroup each (two launches: parts 1 and 2)
 // inv (n_pad x NB doubles): per panel the explicit inverse of its NB x NB diagonal block, transposed -- what the vector solves use
 int launch_inv512(hipStream_t s, const double* packed, int64_t n_pad, const double* winv, double* inv, int64_t p_begin, int64_t p_end);
 int launch_service_gate(hipStream_t s, int64_t n_pad, int* info_dev, void* sync, int launches);

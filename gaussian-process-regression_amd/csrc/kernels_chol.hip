@@ -1666,11 +1666,21 @@ __device__ __forceinline__ void panel_next_diag_role(double* smem, const double*
 // everything in its left-looking pass, k ascending), the look-ahead strips are solved for every panel that has rows below it.
 __global__ __launch_bounds__(512) void panel_service_kernel(double* packed, int64_t n_pad, double* winv, int* info, PanelSync* sy_base,
                                                             int* ready, int P, unsigned long long* trace, double* inv, int p_begin, int p_end,
-                                                            int split) {
+                                                            int split, int part) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int role = blockIdx.x;
   const int t = threadIdx.x, team = t >> 8, tid = t & 255;
   if (t == 0) __hip_atomic_fetch_add(&ready[3 * P], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident: see service_gate_kernel
+  // (Putting the factor role and its four helpers behind ONE L2 -- a grid of 8 x 5 with the five of them on workgroups 0, 8, 16, 24, 32,
+  //  the dealing to XCDs being round robin -- was measured and is SLOWER: n = 8192 5.43 -> 5.67 ms, 16384 27.3 -> 27.5; the other twenty
+  //  roles then crowd four XCDs and the look-ahead strips fall 70 us behind.  profiles/r03_chain_split.txt.)
+  // part 0: the whole service in one launch (role = workgroup).  SHARED service (service_shared): two launches -- part 1 the factor role and
+  // the chain helpers (8 waves each: a CU of their own), part 2 the twenty 4-wave roles with only a GEMM team's LDS, so that ONE workgroup of
+  // the sweep kernel fits beside each of them and has the CU's matrix cores while the role waits for its flags.
+  const int role = part == 0 ? (int)blockIdx.x : part == 1 ? (blockIdx.x == 0 ? 0 : SERVICE_H0 + (int)blockIdx.x - 1) : 1 + (int)blockIdx.x;
+  if (part == 2) __builtin_amdgcn_s_setprio(3);   // beside throughput work on the same SIMDs: the role's instructions go first
+#ifdef GPRC_CHAIN_PROF
+  if (t == 0 && (role == 0 || role >= SERVICE_H0)) g_chain_prof[56 + (role == 0 ? 0 : 1 + role - SERVICE_H0)] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;
+#endif
   if (role >= SERVICE_H0) { if (!split) return; }    // the chain helpers: all 8 waves
   else if (role >= 1 && team == 1) return;           // every other role but the factor role is one 4-wave team
   if (role >= SERVICE_INV0 && role < SERVICE_H0 && !inv) return;
@@ -2203,11 +2213,25 @@ std::string wait_timeout_report() {
   return out + (v[0] > 8 ? "; ... " + std::to_string(v[0]) + " in all]" : "]");
 }
 
+// The SHARED service.  A service workgroup asks for the factor role's 149 KB of LDS, so nothing else fits on its CU -- 21 to 25 CUs
+// that, where the update is the bound, mostly sleep on their flags.  From n_pad = 13312 on, the 4-wave roles (all but the factor role and
+// the chain helpers, whose 8 waves x 256 VGPRs fill a CU) are launched on their own, on a second side stream, with a GEMM team's LDS only
+// (launch_panel_service, part 2): ONE sweep workgroup then fits beside each of them and has the CU's matrix cores while the role waits.
+// Measured, same box (profiles/r03_chain_split.txt): n = 14336 19.45 -> 19.07 ms, 16384 27.3 -> 26.4, 18432 37.55 -> 35.97, 24576
+// 79.7 -> 78.9, 32768 172.5 -> 170.4, 65536 unchanged; 12288 and below unchanged or slower (the chain's own tiles run at half rate
+// beside a busy sweep workgroup), hence the threshold.  Raising the roles' wave priority (s_setprio 3) changes nothing measurable; it
+// stays.  GPRC_SERVICE_SHARE=0 / 1 forces it off / on (from n_pad = 10752, where the sweep runs two workgroups per CU).
+bool service_shared(int64_t n_pad) {
+  static const int v = [] { const char* e = std::getenv("GPRC_SERVICE_SHARE"); return e ? std::atoi(e) : -1; }();
+  return n_pad >= 10752 && (v >= 0 ? v != 0 : n_pad >= 13312);
+}
+
 // workgroups the service keeps resident (a CU each)
 int service_workgroups(bool with_inverse, int64_t n_pad) { return SERVICE_INV0 + (with_inverse ? TPP : 0) + (chain_split(n_pad) ? CHAIN_HELPERS : 0); }
 
+// part: 0 the whole service; 1 / 2 the two launches of the shared service (on two streams: they run side by side)
 int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* winv, int* info_dev, void* sync, void* trace, double* inv,
-                         int64_t p_begin, int64_t p_end) {
+                         int64_t p_begin, int64_t p_end, int part) {
   static bool attr_set[MAX_DEVICES] = {};
   const size_t smem = PB_SMEM_DOUBLES * sizeof(double);
   int dev = 0;
@@ -2220,8 +2244,9 @@ int launch_panel_service(hipStream_t s, double* packed, int64_t n_pad, double* w
   PanelSync* sy = reinterpret_cast<PanelSync*>(sync);
   int* ready = reinterpret_cast<int*>(static_cast<char*>(sync) + (size_t)P * sizeof(PanelSync));
   ProfScope ps(s, PK_PANEL_FUSED, 0.0, 0.0);
-  hipLaunchKernelGGL(panel_service_kernel, dim3(SERVICE_WGS), dim3(512), smem, s, packed, n_pad, winv, info_dev, sy, ready, (int)P,
-                     static_cast<unsigned long long*>(trace), inv, (int)p_begin, (int)p_end, chain_split(n_pad) ? 1 : 0);
+  const unsigned grid = part == 0 ? SERVICE_WGS : part == 1 ? 1 + CHAIN_HELPERS : SERVICE_H0 - 1;
+  hipLaunchKernelGGL(panel_service_kernel, dim3(grid), dim3(512), part == 2 ? G_SMEM_DOUBLES * sizeof(double) : smem, s, packed, n_pad, winv, info_dev, sy,
+                     ready, (int)P, static_cast<unsigned long long*>(trace), inv, (int)p_begin, (int)p_end, chain_split(n_pad) ? 1 : 0, part);
   GPRC_LAUNCH_CHECK();
   return 0;
 }
@@ -2324,7 +2349,9 @@ int launch_trailing_sweep(hipStream_t s, double* packed, int64_t n_pad, int64_t 
   // GPRC_SWEEP_WGS=<n> overrides.
   static const int wgs_env = [] { const char* e = std::getenv("GPRC_SWEEP_WGS"); return e ? std::atoi(e) : 0; }();
   const int per_cu = n_pad < 10752 ? 1 : 2;
-  const int wgs = wgs_env > 0 ? wgs_env : std::max(8, per_cu * (cus - service_wgs));
+  // shared service: the resident 4-wave roles' CUs take ONE sweep workgroup each beside the role
+  const int shared = service_shared(n_pad) ? service_wgs - 1 - (chain_split(n_pad) ? CHAIN_HELPERS : 0) : 0;
+  const int wgs = wgs_env > 0 ? wgs_env : std::max(8, per_cu * (cus - service_wgs) + shared);
   hipLaunchKernelGGL(trailing_sweep_kernel, dim3((unsigned)wgs), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)g0, (int)p_last, (int)q_end,
                      sy, ready, rowcnt, sw, winv, info_dev, static_cast<unsigned long long*>(trace));
   GPRC_LAUNCH_CHECK();

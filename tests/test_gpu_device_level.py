@@ -431,15 +431,19 @@ def test_one_launch_per_panel_under_the_service_is_still_bit_identical(tmp_path)
     assert r.returncode == 0 and "SWEEP0_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("env", [{"GPRC_CHAIN_SPLIT": "0"}, {"GPRC_CHAIN_SPLIT": "1", "GPRC_FACTOR": "40"}, {"GPRC_CHAIN_SPLIT": "1", "GPRC_SWEEP": "0"}],
-                         ids=["unsplit", "split-in-groups", "split-launch-per-panel"])
-def test_both_forms_of_the_panel_chain_are_bit_identical(env):
+@pytest.mark.parametrize("env,sizes", [({"GPRC_CHAIN_SPLIT": "0"}, (1024, 2900, 9100)), ({"GPRC_CHAIN_SPLIT": "1", "GPRC_FACTOR": "40"}, (1024, 2900, 9100)),
+                                       ({"GPRC_CHAIN_SPLIT": "1", "GPRC_SWEEP": "0"}, (1024, 2900, 9100)),
+                                       ({"GPRC_SERVICE_SHARE": "1"}, (11000,)), ({}, (13500,)), ({"GPRC_SERVICE_SHARE": "1", "GPRC_CHAIN_SPLIT": "0", "GPRC_FACTOR": "300"}, (11000,))],
+                         ids=["unsplit", "split-in-groups", "split-launch-per-panel", "shared-service", "shared-service-default", "shared-unsplit-in-groups"])
+def test_both_forms_of_the_panel_chain_are_bit_identical(env, sizes):
     """The split chain (four helper workgroups share the chain's solve / update tiles in 32-row slices, apply every update of a panel's
     diagonal blocks and run the step from W_3 to the next panel's first potf2; the look-ahead strips' early k-chunks ride on the
     next-diagonal-block roles) is the default below n_pad = 20480.  GPRC_CHAIN_SPLIT is read once per process, so child processes
     force the other form, the split form inside the groups of the left-looking schedule (GPRC_FACTOR=40: groups of a few panels, i.e.
     group boundaries where the hand-over to the helpers does not happen) and the split form beside one update launch per panel -- each
-    compared word for word, with the explicit inverses, against the factor_panel / update_trailing sweep."""
+    compared word for word, with the explicit inverses, against the factor_panel / update_trailing sweep.  Likewise the SHARED service
+    (the 4-wave roles in a launch of their own with a GEMM team's LDS, one sweep workgroup beside each: default from n_pad = 13312, forced
+    from 10752), alone, at its default size, and unsplit inside groups."""
     import os
     import subprocess
     import sys
@@ -448,7 +452,7 @@ def test_both_forms_of_the_panel_chain_are_bit_identical(env):
         "import torch\n"
         "import tests.test_gpu_device_level as t\n"
         "from gprc_amd import _native as nat\n"
-        "for n in (1024, 2900, 9100):\n"
+        "for n in %r:\n"
         "    L, ctx, g, K = t._filled(n, seed=7)\n"
         "    a = t._clone(K); w, info = t._new(g)\n"
         "    for p in range(g.P):\n"
@@ -467,6 +471,6 @@ def test_both_forms_of_the_panel_chain_are_bit_identical(env):
         "        assert torch.equal(torch.nan_to_num(inv2), torch.nan_to_num(inv)), n   # (entries below the block diagonal are never written)\n"
         "    ctx.close()\n"
         "print('CHAIN_OK')\n"
-    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), tuple(sizes))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "CHAIN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -35,7 +35,7 @@ for rep in range(4):
     ev = [(v[32 + 4 * j + k], f"factor j={j} " + ["U seen", "potf2 done", "W published"][k]) for j in range(4) for k in range(3)]
     ev += [(v[8 * j + k], f"  helper j={j} " + names[k]) for j in range(4) for k in range(8) if v[8 * j + k]]
     ev.sort()
-    print(f"rep {rep}")
+    print(f"rep {rep}  XCC ids: factor role {v[56]}, helpers {list(v[57:61])}")
     prev = None
     for t, nm in ev:
         print(f"  {(t - t0) / 100.0:8.2f}  {'' if prev is None else f'+{(t - prev) / 100.0:6.2f}'}  {nm}")
