@@ -1230,6 +1230,8 @@ constexpr int GPRC_CHAIN_PROF_PANEL = -1;
 #endif
 constexpr int CHAIN_HELPERS = 4;                  // 32-row slices of a 128-row block
 constexpr int PANEL_DIAG_TILES = TPP * (TPP + 1) / 2;   // lower 128 x 128 tiles of a panel's diagonal block
+constexpr int PANEL_LA_TILES = TPP * TPP;             // tiles of a panel's rows [NB, 2 NB)
+constexpr int AUX_STRIDE = 2 * TPP + PANEL_LA_TILES;  // ints per panel in the sync block's last array: 2 TPP early-chunk flags, then the slice counts of the sweep's head tiles
 constexpr int CHAIN_LDS_LD = 48;                  // doubles per k-slice of the A image: 32 rows + 16 pad (consecutive k-slices 32 banks apart)
 static_assert(CHAIN_HELPERS * 32 == 128 && CHAIN_HELPERS < 8, "SU holds 3-bit counts of 32-row slices (bit 3 of field 0 is a flag)");
 
@@ -1611,7 +1613,6 @@ __global__ __launch_bounds__(256, 2) void inv512_kernel(const double* packed, in
 // update of panel p - 1, which waits only on service flags of panel p - 1; and nothing that waits on the service is launched before
 // the service is resident (service_gate_kernel, the first kernel on the caller's stream).
 // ------------------------------------------------------------------------------------------------
-constexpr int PANEL_LA_TILES = TPP * TPP;             // tiles of a panel's rows [NB, 2 NB)
 constexpr int SERVICE_LA0 = 3;                                   // first look-ahead strip role (one 4-wave team per workgroup)
 constexpr int SERVICE_D0 = SERVICE_LA0 + TPP;                    // first next-diagonal-block role (one tile per workgroup)
 constexpr int SERVICE_INV0 = SERVICE_D0 + PANEL_DIAG_TILES;     // first explicit-inverse role (one block row of inv(L_pp)^T each)
@@ -1691,7 +1692,7 @@ __global__ __launch_bounds__(512) void panel_service_kernel(double* packed, int6
     double* wp = winv + (int64_t)p * TPP * NBI * NBI;
     const bool hand = split && p + 1 < p_end;        // the path W_3 -> next chain goes through the chain helpers
     // aux[p][2 TPP]: flags "block (TPP + i, 2) / (TPP + i, 3) of panel p has its early k-chunks", behind the sweep kernel's flags in the sync block
-    int* aux = ready + 3 * P + 16 + 2 * P * TPP * P + 8 * P + P * TPP * P * TPP + (int64_t)p * 2 * TPP;
+    int* aux = ready + 3 * P + 16 + 2 * P * TPP * P + 8 * P + P * TPP * P * TPP + (int64_t)p * AUX_STRIDE;
     if (role <= 2) {
       if (role == 0) SERVICE_STAMP(p, 14);
       if (p > p_begin) {
@@ -1885,6 +1886,7 @@ struct SweepSync {          // views into the sync block behind PanelSync[P], re
   int* stripdone;           // [P][TPP P]
   int* rest_ticket;         // [P][8]
   int* ver;                 // [P][TPP P][TPP]
+  int* aux;                 // [P][AUX_STRIDE]: from 2 TPP on, the finished 32-row slices of the head tiles of the update INTO panel q (sweep_slice_32)
 };
 
 // a ticket of counter ctr, or `limit` when it is used up (one lane; one device-scope round trip -- a counter past its limit is harmless)
@@ -1941,7 +1943,60 @@ __device__ __forceinline__ void sweep_publish(int* flag, int value, int* ctr, bo
   }
 }
 
-struct SweepItem { int kind, p, s, local, strip, flags; };   // kind 0: tile (s, local) of panel p's update; 1: strip of panel p + 1; -1: nothing left
+// 32 rows x 128 columns of C -= A B^T over K columns (a multiple of 128) on ONE 4-wave workgroup: chain_slice_32's scheme (the A rows of a
+// 128-column chunk through LDS, each wave's B rows straight into registers, write-through stores), wave w the columns [32 w, 32 w + 32).
+// Every element: acc = C, then the k-steps ascending with the negate-A bit -- gemm_tile_128's arithmetic, identical bits.
+__device__ __forceinline__ void sweep_slice_32(double* C_, int64_t ldc, const double* A_, int64_t lda, const double* B_, int64_t ldb, int K, double* lds_) {
+  typedef __attribute__((address_space(1))) double gdouble;
+  typedef __attribute__((address_space(3))) double ldouble;
+  gdouble* C = (gdouble*)C_;
+  const gdouble* A = (const gdouble*)A_;
+  const gdouble* B = (const gdouble*)B_;
+  ldouble* lds = (ldouble*)lds_;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int fk = lane >> 4, fr = lane & 15;
+  double4_t acc[2][2];
+  gdouble* Cw = C + fr + (int64_t)(32 * wave + fk) * ldc;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][n][r] = Cw[16 * m + (int64_t)(16 * n + 4 * r) * ldc];
+  for (int k0 = 0; k0 < K; k0 += 128) {
+    const gdouble* asrc = A + 16 * (t & 1) + (int64_t)(k0 + (t >> 1)) * lda;   // thread t: rows [16 (t & 1), +16) of k-slice t >> 1
+    double av[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) av[i] = asrc[i];
+    const gdouble* bsrc = B + (32 * wave + fr) + (int64_t)(k0 + fk) * ldb;
+    double b0[32], b1[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) { b0[s] = bsrc[(int64_t)(4 * s) * ldb]; b1[s] = bsrc[16 + (int64_t)(4 * s) * ldb]; }
+    __syncthreads();                                   // the previous chunk's LDS reads are over
+    ldouble* adst = lds + (t >> 1) * CHAIN_LDS_LD + 16 * (t & 1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) adst[i] = av[i];
+    __syncthreads();
+    const ldouble* ap = lds + fk * CHAIN_LDS_LD + fr;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const double a0 = ap[4 * s * CHAIN_LDS_LD], a1 = ap[4 * s * CHAIN_LDS_LD + 16];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[s], a0, acc[0][0], 0, 0, 1);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[s], a1, acc[1][0], 0, 0, 1);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[s], a0, acc[0][1], 0, 0, 1);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[s], a1, acc[1][1], 0, 0, 1);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) __hip_atomic_store(&Cw[16 * m + (int64_t)(16 * n + 4 * r) * ldc], acc[m][n][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct SweepItem { int kind, p, s, local, strip, flags; };   // kind 0: tile (s, local) of panel p's update; 1: strip of panel p + 1; 2: rows [32 strip, +32) of head tile `local`; -1: nothing left
 constexpr int SWEEP_SIG_D2 = 1, SWEEP_FIRST = 2, SWEEP_LAST = 4;
 
 // One lane's view of the ticket order (see the kernel): which panel it is at, which counter, and that panel's item counts.
@@ -1964,9 +2019,13 @@ struct SweepCursor {
 
 // panels p in [p_begin, p_last): the update of panel p over the targets (p, q_end) (without the next diagonal block) and the
 // ordinary strips of panel p + 1.  The caller makes sure p_last - 1 still has something to do (p_last + 1 < P, p_last < q_end).
+// CORE: the tile loop of gemm_tile_128 -- 1 (first interleaved loop) where two sweep workgroups share a CU, 2 (no VALU instruction in the
+// loop) where ONE workgroup has the CU (n_pad < 10752): there the faster tile pays (n = 8192 5.47 -> 5.27 ms); beside a second workgroup
+// it costs 5-8 % (12288 13.4 -> 14.3, 16384 26.6 -> 27.5, 32768 171.6 -> 173.7; same box, profiles/r03_chain_split.txt).
+template <int CORE>
 __global__ __launch_bounds__(256, 2) void trailing_sweep_kernel(double* packed, int64_t n_pad, int p_begin, int p_last, int q_end, PanelSync* sy_base,
                                                                 int* ready, int* rowcnt, SweepSync sw, double* winv, int* info,
-                                                                unsigned long long* trace) {
+                                                                unsigned long long* trace, int head_slices) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ SweepItem sh_item;
   __shared__ int sh_dead;
@@ -1986,10 +2045,15 @@ __global__ __launch_bounds__(256, 2) void trailing_sweep_kernel(double* packed, 
     while (cur.p < p_last) {
       it.p = cur.p;
       if (cur.phase == 0) {
-        const int lim = cur.n_first + cur.nstrips;
-        const int t = sweep_take(&sy_base[cur.p].ticket, lim);
+        // (CORE == 2, one workgroup per CU: the chain is the bound, and the first 16 head tiles -- the next panel's rows [NB, 2 NB), which
+        //  release that panel's look-ahead strips -- are dealt in four 32-row slices each: 64 items of ~25 us instead of 16 tiles of ~100)
+        const int extra = (CORE == 2 && head_slices && cur.n_first >= PANEL_LA_TILES) ? 3 * PANEL_LA_TILES : 0;
+        const int lim = cur.n_first + cur.nstrips + extra;
+        int t = sweep_take(&sy_base[cur.p].ticket, lim);
         if (t >= lim) { cur.phase = 1; continue; }
         if (t == 0) it.flags |= SWEEP_FIRST;
+        if (extra && t < 4 * PANEL_LA_TILES) { it.kind = 2; it.local = DIAG + (t >> 2); it.strip = t & 3; return; }
+        t -= extra;
         if (t < cur.n_first) { it.kind = 0; it.local = DIAG + t; }
         else { it.kind = 1; it.strip = 2 * TPP + (t - cur.n_first); }
         return;
@@ -2034,8 +2098,8 @@ __global__ __launch_bounds__(256, 2) void trailing_sweep_kernel(double* packed, 
     PanelSync* sy = sy_base + p;
     if (it.flags & SWEEP_FIRST) SERVICE_STAMP(p, 9);
     if (it.flags & SWEEP_LAST) SERVICE_STAMP(p, 13);
-    if (it.kind == 0) {
-      // ---- one tile of the update with panel p: target q = p + 1 + s, tile (tr, tc) of that panel
+    if (it.kind == 0 || it.kind == 2) {
+      // ---- one tile of the update with panel p: target q = p + 1 + s, tile (tr, tc) of that panel (kind 2: 32 rows of it)
       const int q = p + 1 + it.s, local = it.local;
       int tr, tc;
       if (local < DIAG) {
@@ -2065,7 +2129,21 @@ __global__ __launch_bounds__(256, 2) void trailing_sweep_kernel(double* packed, 
       // (CORE = 1: see the loops' comments.  WT: the tile is stored write-through, so that its publication needs no write-back of the XCD's
       //  L2 -- a release fence per tile, by ~60 workgroups per XCD, each flushing what all of them have dirtied since the last one, was
       //  2 % of the mid-size factorisation: n = 16384 27.42 -> 26.84 ms, 8192 5.98 -> 5.81, same box)
-      gemm_tile_128<false, false, false, false, false, true, 1, true>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, Lp + (int64_t)tr * 128, ldp, Lp + (int64_t)tc * 128, ldp, NB, smem);
+      if constexpr (CORE == 2) if (it.kind == 2) {
+        sweep_slice_32(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq + 32 * it.strip, ldq, Lp + (int64_t)tr * 128 + 32 * it.strip, ldp, Lp + (int64_t)tc * 128, ldp, NB, smem);
+        // the slice is stored (write-through): count it; the fourth one publishes the tile as a whole tile's holder would
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0 &&
+            (__hip_atomic_fetch_add(sw.aux + (int64_t)q * AUX_STRIDE + 2 * TPP + (local - DIAG), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 3) == 3) {
+          __hip_atomic_store(verp, stage + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(&ready[P + q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        SWEEP_ADD(5, 0ull, 1ull);
+        if (it.flags & SWEEP_FIRST) SERVICE_STAMP(p, 11);
+        continue;
+      }
+      gemm_tile_128<false, false, false, false, false, true, CORE, true>(Cq + (int64_t)tr * 128 + (int64_t)tc * 128 * ldq, ldq, Lp + (int64_t)tr * 128, ldp, Lp + (int64_t)tc * 128, ldp, NB, smem);
       SWEEP_T(tw2);
       int* ctr = nullptr;
       if (it.s == 0) ctr = tr < 2 * TPP ? &ready[P + q] : &rowcnt[(int64_t)q * TPP * P + tr];
@@ -2174,7 +2252,7 @@ static int ensure_gemm_attrs();
 // ... and behind them the persistent sweep's flags (trailing_sweep_kernel): stripdone[P][TPP P], rest_ticket[P][8], ver[P][TPP P][TPP]
 size_t panel_service_sync_bytes(int64_t P) {
   return (size_t)P * sizeof(PanelSync) + (3 * (size_t)P + 16) * sizeof(int) + (size_t)P * TPP * P * sizeof(int) +
-         ((size_t)P * TPP * P + 8 * (size_t)P + (size_t)P * TPP * P * TPP) * sizeof(int) + (size_t)P * 2 * TPP * sizeof(int);   // ... and aux[P][2 TPP]
+         ((size_t)P * TPP * P + 8 * (size_t)P + (size_t)P * TPP * P * TPP) * sizeof(int) + (size_t)P * AUX_STRIDE * sizeof(int);   // ... and aux[P][AUX_STRIDE]
 }
 
 // sync: panel_service_sync_bytes(P) bytes of device memory, zeroed by the caller (stream-ordered before this launch)
@@ -2340,6 +2418,7 @@ int launch_trailing_sweep(hipStream_t s, double* packed, int64_t n_pad, int64_t 
   sw.stripdone = rowcnt + P * TPP * P;
   sw.rest_ticket = sw.stripdone + P * TPP * P;
   sw.ver = sw.rest_ticket + 8 * P;
+  sw.aux = sw.ver + P * TPP * P * TPP;
   int dev = 0, cus = 0;
   GPRC_HIP(hipGetDevice(&dev));
   GPRC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -2352,8 +2431,13 @@ int launch_trailing_sweep(hipStream_t s, double* packed, int64_t n_pad, int64_t 
   // shared service: the resident 4-wave roles' CUs take ONE sweep workgroup each beside the role
   const int shared = service_shared(n_pad) ? service_wgs - 1 - (chain_split(n_pad) ? CHAIN_HELPERS : 0) : 0;
   const int wgs = wgs_env > 0 ? wgs_env : std::max(8, per_cu * (cus - service_wgs) + shared);
-  hipLaunchKernelGGL(trailing_sweep_kernel, dim3((unsigned)wgs), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)g0, (int)p_last, (int)q_end,
-                     sy, ready, rowcnt, sw, winv, info_dev, static_cast<unsigned long long*>(trace));
+  static const int head_slices = [] { const char* e = std::getenv("GPRC_HEAD_SLICES"); return e ? std::atoi(e) : 1; }();   // 0: whole head tiles (A/B switch)
+  if (per_cu == 1 && wgs_env <= 0)
+    hipLaunchKernelGGL(trailing_sweep_kernel<2>, dim3((unsigned)wgs), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)g0, (int)p_last,
+                       (int)q_end, sy, ready, rowcnt, sw, winv, info_dev, static_cast<unsigned long long*>(trace), head_slices);
+  else
+    hipLaunchKernelGGL(trailing_sweep_kernel<1>, dim3((unsigned)wgs), dim3(256), G_SMEM_DOUBLES * sizeof(double), s, packed, n_pad, (int)g0, (int)p_last,
+                       (int)q_end, sy, ready, rowcnt, sw, winv, info_dev, static_cast<unsigned long long*>(trace), 0);
   GPRC_LAUNCH_CHECK();
   return 0;
 }
@@ -2374,7 +2458,8 @@ static int ensure_gemm_attrs() {
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_strips_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_service_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_sweep_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_sweep_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(inv512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_left_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   GPRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trailing_range_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
