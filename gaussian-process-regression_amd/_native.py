@@ -121,6 +121,7 @@ PROTOTYPES = {
     "gprc_prof_enable": (C.c_int, [C.c_int]),
     "gprc_prof_panel_trace": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), C.c_int]),
     "gprc_prof_service_trace": (C.c_int, [_vp, C.POINTER(_i64), C.c_int]),
+    "gprc_prof_wait_timeout": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "gprc_prof_reset": (C.c_int, []),
     "gprc_prof_kinds": (C.c_int, []),
     "gprc_prof_summary": (C.c_int, [C.c_int, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

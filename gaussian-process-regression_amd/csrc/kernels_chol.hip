@@ -1084,7 +1084,7 @@ constexpr unsigned long long WAIT_LIMIT_TICKS = 400000000ULL;   // 4 s
 //  field 0: that tile has received the k-chunks 0..2 (role SERVICE_D0).  R[0]: block (4, 3) is ready for its solve (look-ahead strip 4))
 
 // Who gave up, and on what: every wait of a factorisation that runs out its bound -- and every wait that was still unsatisfied when it
-// saw that somebody else had (site + 10) -- leaves a record for the host (wait_timeout_report, gprc_debug_wait_timeout): up to
+// saw that somebody else had (site + 10) -- leaves a record for the host (wait_timeout_report, gprc_prof_wait_timeout): up to
 // WAIT_DIAG_RECORDS records of 8 ints behind a counter -- [0] site (1 flag, 2 count, 3 field, 4 chain, 5 sweep, 6 gate), [1] blockIdx.x,
 // [2] gridDim.x, [3] the value needed, [4] the value seen, [5] the awaited word's index inside its panel's PanelSync (or its distance
 // from it), [6] threads per workgroup, [7] low 32 bits of the PanelSync's address (which panel)
@@ -2170,8 +2170,9 @@ __global__ __launch_bounds__(256, 2) void trailing_sweep_kernel(double* packed, 
 }
 }  // namespace
 }  // namespace gprc
-// tools only (not part of include/gprc_native.h): the raw records of the timed-out waits, see wait_diag; clears them
-extern "C" __attribute__((visibility("default"))) int gprc_debug_wait_timeout(int* out, int ints) {   // out[0]: records written; 8 ints per record from out[8]
+// include/gprc_native.h: the raw records of the timed-out waits, see wait_diag; clears them
+extern "C" __attribute__((visibility("default"))) int gprc_prof_wait_timeout(int* out, int ints) {   // out[0]: records written; 8 ints per record from out[8]
+  if (!out || ints < 8) return -1;
   const size_t bytes = sizeof(int) * (size_t)std::min(ints, 8 * (gprc::WAIT_DIAG_RECORDS + 1));
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gprc::g_wait_diag), bytes) != hipSuccess) return -1;
   static const int z[8 * (gprc::WAIT_DIAG_RECORDS + 1)] = {};

@@ -205,6 +205,9 @@ GPRC_API int gprc_dev_factor_subpanel(gprc_ctx* ctx, double* packed, int64_t n_p
  * the factor_panel / update_trailing sweep: the panels in groups, a left-looking pass per group, inside the group two persistent
  * launches side by side -- the factor service (the panels' dependent chains) and the sweep kernel (every other tile and strip of the
  * group, dealt by tickets; GPRC_SWEEP=0: one launch per panel instead); one group below n_pad = 20480): results bit-identical to that sweep.
+ * Below n_pad = 20480 the chain's 128^3 tiles are split in 32-row slices over four helper workgroups of the service (GPRC_CHAIN_SPLIT=0 / 1
+ * forces the form); from n_pad = 13312 the service's 4-wave roles share their CUs with one sweep workgroup each (GPRC_SERVICE_SHARE=0 / 1).
+ * Every combination gives the same bits.
  * info_dev: one device int, zeroed by the caller, receives LAPACK's info (first non-PD leading minor) if any.
  * inv: NULL, or gprc_solve_inv_size(n_pad) doubles that receive what gprc_dev_solve_prepare would compute for all panels. */
 GPRC_API int gprc_dev_factor_all(gprc_ctx* ctx, double* packed, int64_t n_pad, double* winv, int* info_dev, double* inv);
@@ -364,6 +367,13 @@ GPRC_API int gprc_prof_panel_trace(gprc_ctx* ctx, int side, int64_t* ticks_out, 
  * look-ahead rows, [11] has published, [12] first tile of the block after the next published, [13] last tile done.
  * panels <= 48.  Measurement only. */
 GPRC_API int gprc_prof_service_trace(gprc_ctx* ctx, int64_t* ticks_out, int panels);
+/* When a factorisation ends in a device-side wait timeout (info = -99: the factor service's persistent launch and the caller's kernels did
+ * not run concurrently, or a dependency never arrived), every wait that was unsatisfied at that moment has left a record: out[0] = records
+ * written, then 8 ints per record from out[8] on -- site (1 flag, 2 count, 3 field, 4 chain helper, 5 sweep kernel, 6 residency gate; +10: the
+ * wait was a bystander that left because somebody else's bound had run out), workgroup, grid size, value needed, value seen, index of the
+ * awaited word inside its panel's flags, threads per workgroup, low 32 bits of those flags' address.  ints: capacity of out (at most
+ * 8 * 49 are written).  Reading clears the records.  The fit entry points put the same records, as text, into gprc_last_error.  Diagnostics only. */
+GPRC_API int gprc_prof_wait_timeout(int* out, int ints);
 GPRC_API int gprc_prof_reset(void);
 GPRC_API int gprc_prof_kinds(void);
 GPRC_API int gprc_prof_summary(int kind, int64_t* count_out, double* ms_out, double* flops_out, double* bytes_out);

@@ -35,7 +35,7 @@ for r in range(rounds):
         torch.cuda.synchronize()
         count += 1
         if int(info[0]) < 0:
-            rec = (ctypes.c_int * 392)(); L.gprc_debug_wait_timeout(rec, 392)
+            rec = (ctypes.c_int * 392)(); L.gprc_prof_wait_timeout(rec, 392)
             print(f"round {r} n={n}: info={int(info[0])}; waits that gave up [site (+10: bystander), workgroup, grid, needed, saw, word, threads, sy]:", flush=True)
             for k in range(min(rec[0], 48)): print("   ", list(rec)[8 * (k + 1): 8 * (k + 2)], flush=True)
             sys.exit(3)

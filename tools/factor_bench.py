@@ -34,7 +34,7 @@ for n in [int(a) for a in sys.argv[1:]] or [8192, 16384]:
         if rep: best = min(best, dt)
     if int(info[0]) < 0:                                  # a device-side wait gave up: who, and on what (kernels_chol.hip: wait_diag)
         import ctypes
-        rec = (ctypes.c_int * 392)(); L.gprc_debug_wait_timeout(rec, 392)
+        rec = (ctypes.c_int * 392)(); L.gprc_prof_wait_timeout(rec, 392)
         print(f"n={n} info={int(info[0])} waits that gave up [site (+10: bystander), workgroup, grid, needed, saw, word, threads, sy]:", flush=True)
         for k in range(min(rec[0], 48)): print("   ", list(rec)[8 * (k + 1): 8 * (k + 2)], flush=True)
         continue
