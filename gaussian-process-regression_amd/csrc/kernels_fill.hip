@@ -98,6 +98,15 @@ __device__ __forceinline__ double finish(double s, const KernelSpec& ks) {
     const double c = ks.p[2], rc = ks.p[3];                                   // l^2 and its reciprocal (make_fill_spec)
     double u = s * rc;
     u = fma(fma(-u, c, s), rc, u);
+    // gamma = 0.5, 1, 1.5 (flagged by make_fill_spec in p[4] = 2 gamma; gamma = 1 is the exponential kernel): u^(gamma / 2) from one or two square
+    // roots -- correctly rounded each -- instead of a log and an exp
+    const int h = (int)ks.p[4];
+    if (h != 0) {                       // (wave-uniform: a launch constant)
+      const double r = sqrt(u);
+      if (h == 2) return exp(-r);
+      const double rr = sqrt(r);
+      return exp(h == 1 ? -rr : -(r * rr));
+    }
     return exp(-exp(0.5 * g * log(u)));
   }
   else {
@@ -265,6 +274,8 @@ KernelSpec make_fill_spec(const KernelSpec& ks) {
   if (ks.id == GPRC_GAMMAEXP) {
     d.p[2] = ks.p[0] * ks.p[0];
     d.p[3] = 1.0 / d.p[2];
+    const double h = 2.0 * ks.p[1];                  // gamma = 0.5, 1, 1.5: the square-root form of the power (finish<GPRC_GAMMAEXP>)
+    d.p[4] = (h == 1.0 || h == 2.0 || h == 3.0) ? h : 0.0;
   }
   if (ks.id == GPRC_RATQUAD) {
     d.p[2] = 2.0 * ks.p[1] * (ks.p[0] * ks.p[0]);   // 2 * alpha * l^2, in R's evaluation order

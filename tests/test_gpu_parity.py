@@ -177,11 +177,18 @@ KERNELS = [("constant", dict(c=1.7)), ("linear", dict(sigma=0.7)), ("polynomial"
            ("rationalquadratic", dict(l=0.9, alpha=3.5)), ("rationalquadratic", dict(l=1.2, alpha=0.5))]   # half-integer alpha: the rsqrt form
 
 
+# the fill's other power forms (kernel matrices only: some of these are too ill-conditioned for the GPR-level comparisons below)
+FILL_EXTRA = [("gammaexp", dict(l=1.1, gamma=1.0)), ("gammaexp", dict(l=0.8, gamma=0.5)),   # gamma = 0.5, 1, 1.5: the square-root form
+              ("gammaexp", dict(l=0.9, gamma=1.3)),                                          # general gamma: exp(gamma / 2 log(s / l^2))
+              ("polynomial", dict(sigma=0.5, p=5.0)),                                        # integer degree 3..8: multiplications
+              ("polynomial", dict(sigma=40.0, p=2.5))]                                       # any other degree: R_pow (sigma keeps the base positive up to d = 37)
+
+
 @pytest.mark.parametrize("d,nA,nB", [(1, 1, 1), (1, 5, 3), (2, 130, 67), (8, 257, 300), (20, 64, 129), (37, 300, 10)])
 def test_covariance_matrix_all_kernels(d, nA, nB):
     rng = np.random.default_rng(100 + d)
     A, B = rng.uniform(-1, 1, (d, nA)), rng.uniform(-1, 1, (d, nB))
-    for kind, par in KERNELS + [("linear", dict(sigma=list(rng.uniform(0.2, 1.5, d))))]:
+    for kind, par in KERNELS + FILL_EXTRA + [("linear", dict(sigma=list(rng.uniform(0.2, 1.5, d))))]:
         k = kfun(kind, par)
         ref = orc.kernel_matrix(orc.KERNEL_IDS[kind], oracle_params(kind, par), A, B)
         got = covariance_matrix(A, B, k)
